@@ -1,0 +1,200 @@
+/*
+ * wcqp.h — C ABI of the MI355X-native batched QP solve path that replaces the
+ * osqp-eigen / qpOASES calls behind the reference's WalkingController
+ * (DCM-MPC) and WalkingQPIK (Jacobian QP-IK) solver interfaces.
+ *
+ * Citations are relative to /root/reference/modules/Walking_module ("WM/").
+ *
+ * The reference has no FFI: its boundary is two C++ class surfaces
+ * (WM/include/WalkingDCMModelPredictiveController.hpp:190-250 with
+ * WM/include/MPCSolver.hpp:57-138, and WM/include/WalkingQPInverseKinematics.hpp:81-208).
+ * Every entry point below names the reference call(s) it stands in for.  Batch = 1
+ * reproduces the per-robot call; batch = B solves B independent robot instances.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the ABI; every function returns WCQP_OK (0) or
+ *     a negative WCQP_E_* code; per-instance results carry a WCQP_STATUS_* code
+ *     (the batch analogue of the reference's `bool` returns).
+ *   - all arithmetic is IEEE fp64 like the reference.
+ *   - `*_device` entry points take DEVICE pointers and a hipStream_t (as void*); they
+ *     enqueue work and return without synchronising (graph-capturable: no
+ *     allocation, no sync inside).  `*_host` entry points take HOST pointers,
+ *     stage through the handle's own device buffers and synchronise.
+ *   - the handle owns every buffer it allocates; the caller owns inputs/outputs;
+ *     no pointer is retained past a call.  A handle is single-caller (like the
+ *     reference's solvers, which are only touched under WalkingModule's m_mutex,
+ *     WM/src/WalkingModule.cpp:429).
+ */
+#ifndef WCQP_H
+#define WCQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WCQP_VERSION 100
+
+/* return codes */
+#define WCQP_OK              0
+#define WCQP_E_INVALID      (-1)   /* bad argument / NULL pointer                      */
+#define WCQP_E_UNSUPPORTED  (-2)   /* size outside what the kernels are built for      */
+#define WCQP_E_NUMERIC      (-3)   /* host-side constant precomputation failed         */
+#define WCQP_E_HIP          (-4)   /* HIP runtime error (no device, launch failure...) */
+#define WCQP_E_NOMEM        (-5)
+
+/* per-instance status */
+#define WCQP_STATUS_SOLVED        0
+#define WCQP_STATUS_MAX_ITER      1   /* active-set iteration budget exhausted            */
+#define WCQP_STATUS_INFEASIBLE    2   /* constraints admit no point                       */
+#define WCQP_STATUS_OUTSIDE_HULL  3   /* MPC: margin(u0) < -convex_hull_tolerance
+                                         (WM/src/WalkingDCMModelPredictiveController.cpp:513-517) */
+#define WCQP_STATUS_NUMERIC       4   /* non-positive pivot (KKT not regular)             */
+
+#define WCQP_HULL_ROWS   8            /* hull rows are padded to 8 per instance           */
+#define WCQP_MAX_DOF     32
+#define WCQP_IK_STATE_LEN 87          /* doubles in the packed per-instance pose block    */
+
+const char* wcqp_strerror(int code);
+int wcqp_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never initialises a context) */
+int wcqp_device_count(void);
+
+/* =====================================================================================
+ * DCM-MPC  — replaces  WalkingController::{initialize, setConvexHullConstraint,
+ *            setFeedback, setReferenceSignal, solve, getControllerOutput}
+ *            (WM/src/WalkingDCMModelPredictiveController.cpp:311-535) and the
+ *            MPCSolver / OsqpEigen::Solver object they drive (WM/src/MPCSolver.cpp:16-322).
+ * ===================================================================================== */
+typedef struct wcqp_mpc_params {
+    int32_t horizon;              /* N = round(controllerHorizon / sampling_time), cpp:182-187 */
+    double  sampling_time;        /* cpp:182                                                   */
+    double  com_height;           /* cpp:224-229                                               */
+    double  gravity;              /* cpp:230 (default 9.81)                                    */
+    double  Q[4];                 /* state weight, row-major 2x2 (stateWeightTriplets)         */
+    double  R[4];                 /* input weight, row-major 2x2 (inputWeightTriplets)         */
+    double  convex_hull_tolerance;/* cpp:306                                                   */
+    double  feas_tol;             /* feasibility slack of a candidate vertex; 0 -> 1e-10       */
+} wcqp_mpc_params;
+
+typedef struct wcqp_mpc_s* wcqp_mpc_t;
+
+/* WalkingController::initialize/initializeMatrices (cpp:170-243, 311-362): builds P,
+ * A_eq and the gradient sub-matrix, then condenses the batch-constant equality KKT
+ * once on the host (u0 = sum_i Gr_i r_i + Gx x0 + Gu u_prev - Sigma0 A_h' mu). */
+int wcqp_mpc_create(const wcqp_mpc_params* params, wcqp_mpc_t* out);
+int wcqp_mpc_destroy(wcqp_mpc_t h);
+
+/* Host-side introspection of the condensed constants (tests):
+ * Gr[(N+1)*4], Gx[4], Gu[4], Sigma0[4], all row-major 2x2 blocks. */
+int wcqp_mpc_get_condensed(wcqp_mpc_t h, double* Gr, double* Gx, double* Gu, double* Sigma0);
+/* Dense copies of the reference's constant blocks for parity checks against
+ * initializeMatrices: P[n*n], A_eq[n_x*n], grad_sub[n_u*2]; n = 4N+2. */
+int wcqp_mpc_get_matrices(wcqp_mpc_t h, double* P, double* A_eq, double* grad_sub);
+
+/*
+ * One MPC tick for `batch` instances — the contents of the reference's "MPC" profiler
+ * bracket (WM/src/WalkingModule.cpp:604-636):
+ *   hull_A[B][8][2], hull_b[B][8], hull_nc[B]  <- setConvexHullConstraint / MPCSolver::setConstraintsMatrix
+ *                                                 + the hull part of setBounds (MPCSolver.cpp:76-123,149-153);
+ *                                                 rows >= hull_nc[i] are ignored
+ *   x0[B][2]                                   <- setFeedback / setBounds rows 0..1 (MPCSolver.cpp:143-146)
+ *   ref[B][ref_len][2], ref_len >= 1           <- setReferenceSignal / setGradient (MPCSolver.cpp:183-239);
+ *                                                 stages >= ref_len repeat the last one (:200-214)
+ *   u_prev[B][2]                               <- m_output fed back as previousControllerOutput (:244-245)
+ * outputs
+ *   u0[B][2]      first input = desired ZMP    -> getControllerOutput (cpp:510-511, 523-535)
+ *   status[B]     WCQP_STATUS_*                -> the bool of solve() (cpp:491-521)
+ *   active[B]     bit e set <=> hull row e is in the optimal active set       (may be NULL)
+ *   margin[B]     signed distance of u0 to the hull boundary, + inside         (may be NULL)
+ */
+int wcqp_mpc_solve_device(wcqp_mpc_t h, int32_t batch,
+                          const double* x0, const double* ref, int32_t ref_len,
+                          const double* u_prev,
+                          const double* hull_A, const double* hull_b, const int32_t* hull_nc,
+                          double* u0, int32_t* status, uint32_t* active, double* margin,
+                          void* stream);
+int wcqp_mpc_solve_host(wcqp_mpc_t h, int32_t batch,
+                        const double* x0, const double* ref, int32_t ref_len,
+                        const double* u_prev,
+                        const double* hull_A, const double* hull_b, const int32_t* hull_nc,
+                        double* u0, int32_t* status, uint32_t* active, double* margin);
+
+/* =====================================================================================
+ * QP-IK — replaces WalkingQPIK_osqp::solve / WalkingQPIK_qpOASES::solve and the
+ *         OsqpEigen::Solver / qpOASES::SQProblem objects behind them
+ *         (WM/src/WalkingQPInverseKinematics_osqp.cpp:340-428,
+ *          WM/src/WalkingQPInverseKinematics_qpOASES.cpp:284-362).
+ * ===================================================================================== */
+#define WCQP_IK_FORM_QPOASES 0   /* bounds enforced, kappa = 1, feet always corrected        */
+#define WCQP_IK_FORM_OSQP    1   /* joint-limit rows are zero rows (never bind), extra
+                                    k_attFoot on the neck gradient term, zero-twist rule
+                                                               */
+
+typedef struct wcqp_ik_params {
+    int32_t dof;                         /* actuated DoF (23 on iCub); n = dof + 6            */
+    int32_t use_com_as_constraint;       /* qpInverseKinematics.ini:2                          */
+    int32_t form;                        /* WCQP_IK_FORM_*                                     */
+    int32_t max_iter;                    /* active-set changes budget; 0 -> 100 (nWSR, qp.cpp:312) */
+    double  com_weight[9];               /* row-major 3x3, used when !use_com_as_constraint    */
+    double  neck_weight[9];              /* row-major 3x3                                      */
+    double  joint_reg_weights[WCQP_MAX_DOF];
+    double  joint_reg_gains[WCQP_MAX_DOF];
+    double  joint_reg_rad[WCQP_MAX_DOF]; /* jointRegularization already in rad (osqp.cpp:101-102) */
+    double  v_min[WCQP_MAX_DOF];         /* joint velocity limits (WalkingModule.cpp:237-243)  */
+    double  v_max[WCQP_MAX_DOF];
+    double  k_pos_com, k_pos_foot, k_att_foot, k_neck;
+    double  rho;                         /* weight of the A'A term that regularises H; 0 -> 1  */
+    double  tol;                         /* bound-violation tolerance; 0 -> 1e-12              */
+} wcqp_ik_params;
+
+typedef struct wcqp_ik_s* wcqp_ik_t;
+
+/* WalkingQPIK_*::initialize + WalkingQPIK::initializeMatrices
+ * (osqp.cpp:54-133, qp.cpp:53-133, WalkingQPInverseKinematics.cpp:25-116). */
+int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out);
+int wcqp_ik_destroy(wcqp_ik_t h);
+
+/*
+ * One IK tick for `batch` instances — the solver part of the reference's "IK" bracket
+ * (WM/src/WalkingModule.cpp:367-425, 721-740).  n = dof + 6, all matrices row-major:
+ *   J_left[B][6][n], J_right[B][6][n]   <- setLeftFootJacobian / setRightFootJacobian
+ *   J_neck[B][3][n]                     <- rows 3..5 of the 6 x n neck Jacobian, as kept by
+ *                                          setNeckJacobian (WalkingQPInverseKinematics.cpp:214-215)
+ *   J_com[B][3][n]                      <- setCoMJacobian
+ *   q[B][dof]                           <- setRobotState joint positions
+ *   state[B][87]                        <- setRobotState / setDesired* poses, packed:
+ *        p_left 0..2 | R_left 3..11 | p_right 12..14 | R_right 15..23
+ *        pd_left 24..26 | Rd_left 27..35 | pd_right 36..38 | Rd_right 39..47
+ *        R_neck 48..56 | Rd_neck 57..65 (already multiplied by additional_rotation, cpp:143-146)
+ *        com 66..68 | com_des 69..71 | com_vel_des 72..74 | twist_left 75..80 | twist_right 81..86
+ * outputs
+ *   dq[B][dof]                          -> getSolution (osqp.cpp:410-428, qp.cpp:341-362)
+ *   status[B]                           -> the bool of solve()
+ *   active_lower[B], active_upper[B]    bit i set <=> joint i sits on its lower/upper velocity
+ *                                       limit with a positive multiplier          (may be NULL)
+ *   foot_err[B][12]                     -> getLeftFootError | getRightFootError
+ *                                          (osqp.cpp:430-454, qp.cpp:364-401)     (may be NULL)
+ *   iters[B]                            active-set changes performed              (may be NULL)
+ */
+int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
+                         const double* J_left, const double* J_right,
+                         const double* J_neck, const double* J_com,
+                         const double* q, const double* state,
+                         double* dq, int32_t* status,
+                         uint32_t* active_lower, uint32_t* active_upper,
+                         double* foot_err, int32_t* iters,
+                         void* stream);
+int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
+                       const double* J_left, const double* J_right,
+                       const double* J_neck, const double* J_com,
+                       const double* q, const double* state,
+                       double* dq, int32_t* status,
+                       uint32_t* active_lower, uint32_t* active_upper,
+                       double* foot_err, int32_t* iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WCQP_H */

@@ -1,0 +1,578 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under `oracle/` is product code.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module, and only as the *checker*.  The product path
+(`walking-controllers_amd/`) never routes through it.
+
+PARITY UNPINNED: the reference (lia2790/walking-controllers) has no tests, no
+golden vectors and no fixtures for this path, and its arithmetic lives in
+un-vendored, un-pinned third-party solvers (OSQP through osqp-eigen, qpOASES)
+that are absent from this container.  The reference itself is
+C++ against YARP/iDynTree/Eigen and cannot be compiled here.  This file is
+therefore a CPU *restatement* of
+
+  (1) how the reference ASSEMBLES its two QPs (every function cites the
+      reference file:line it follows; citations are relative to
+      /root/reference/modules/Walking_module, "WM/"), and
+  (2) the EXACT fp64 optimum of those QPs (equality-KKT + active set, with a
+      KKT certificate check), which is what "the reference's output" converges
+      to for any correct QP solver; OSQP at its default eps=1e-3 only
+      approximates it.
+
+The OSQP-algorithm restatement (ADMM) and the dense active-set restatement
+that double as the timed CPU baseline live in `oracle/wc_oracle.c`.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+OSQP_INFTY = 1e30  # OsqpEigen::INFTY (upstream constant; WM/src/MPCSolver.cpp:48-49)
+
+
+# --------------------------------------------------------------------------------------
+# A.1  DCM-MPC  (WalkingController + MPCSolver)
+# --------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class MPCParams:
+    """Values of CFG/controllerParams.ini + CFG/dcmWalkingCoordinator.ini:18-20.
+
+    `horizon` is N = round(controllerHorizon / sampling_time)
+    (WM/src/WalkingDCMModelPredictiveController.cpp:182-187).  BASELINE.json
+    benchmarks N = 50; the shipped configuration gives N = 200.
+    """
+    horizon: int = 50
+    sampling_time: float = 0.01
+    com_height: float = 0.53
+    gravity: float = 9.81
+    Q: np.ndarray = dataclasses.field(default_factory=lambda: 7500.0 * np.eye(2))
+    R: np.ndarray = dataclasses.field(default_factory=lambda: 9.0e6 * np.eye(2))
+    convex_hull_tolerance: float = 0.05
+    foot_size: Tuple[Tuple[float, float], Tuple[float, float]] = ((-0.02, 0.05), (-0.025, 0.025))
+
+
+@dataclasses.dataclass
+class MPCConstants:
+    N: int
+    n: int
+    n_x: int
+    n_u: int
+    a: float
+    b: float
+    Q: np.ndarray
+    R: np.ndarray
+    P: np.ndarray          # n x n Hessian
+    A_eq: np.ndarray       # n_x x n
+    grad_sub: np.ndarray   # n_u x 2  (= -Theta' Rtilde e1)
+
+
+def mpc_theta(N: int) -> np.ndarray:
+    """Theta = I_{2N} - (shift by one input block).
+    WM/src/WalkingDCMModelPredictiveController.cpp:23-36."""
+    d = 2 * N
+    th = np.eye(d)
+    th[np.arange(2, d), np.arange(0, d - 2)] = -1.0
+    return th
+
+
+def mpc_constants(p: MPCParams) -> MPCConstants:
+    """One-time constant blocks.
+    WM/src/WalkingDCMModelPredictiveController.cpp:170-243 and helpers :38-168."""
+    N = int(p.horizon)
+    n_x, n_u = 2 * (N + 1), 2 * N
+    n = n_x + n_u
+    Q = np.asarray(p.Q, float).reshape(2, 2)
+    R = np.asarray(p.R, float).reshape(2, 2)
+    theta = mpc_theta(N)                                   # :23-36
+    Rt = np.kron(np.eye(N), R)                             # :38-49
+    Qt = np.kron(np.eye(N + 1), Q)                         # :51-62
+    Pu = theta.T @ Rt @ theta                              # :65-77
+    P = np.zeros((n, n))
+    P[:n_x, :n_x] = Qt                                     # :126-144
+    P[n_x:, n_x:] = Pu
+    e1 = np.zeros((n_u, 2))
+    e1[0, 0] = e1[1, 1] = 1.0
+    grad_sub = -theta.T @ Rt @ e1                          # :148-168
+    omega = math.sqrt(p.gravity / p.com_height)            # :230-231
+    a = math.exp(omega * p.sampling_time)                  # :236
+    b = 1.0 - a                                            # :237
+    A_eq = np.zeros((n_x, n))
+    A_eq[np.arange(n_x), np.arange(n_x)] = -1.0            # :102-103
+    for i in range(N):                                     # :105-123
+        r = 2 * (i + 1)
+        A_eq[r, 2 * i] = a
+        A_eq[r + 1, 2 * i + 1] = a
+        A_eq[r, n_x + 2 * i] = b
+        A_eq[r + 1, n_x + 2 * i + 1] = b
+    return MPCConstants(N, n, n_x, n_u, a, b, Q, R, P, A_eq, grad_sub)
+
+
+def mpc_gradient(c: MPCConstants, ref: np.ndarray, u_prev: np.ndarray,
+                 q_prev: Optional[np.ndarray] = None, reset: bool = True) -> np.ndarray:
+    """q of the QP.  WM/src/MPCSolver.cpp:183-266.
+
+    reset / not-initialised  -> full rebuild (:188-215), padding with ref[-1]
+                                when the deque is shorter than N+1 (:200-214);
+    otherwise               -> shift by one stage and compute stage N only (:216-239).
+    q_u = grad_sub @ u_prev (:244-245)."""
+    N = c.N
+    ref = np.asarray(ref, float).reshape(-1, 2)
+    q = np.zeros(c.n)
+    if q_prev is None or reset:
+        for i in range(N + 1):
+            r = ref[i] if i < ref.shape[0] else ref[-1]
+            q[2 * i:2 * i + 2] = -c.Q @ r
+    else:
+        q[:c.n_x] = q_prev[:c.n_x]
+        q[0:2 * N] = q_prev[2:2 * N + 2]
+        r = ref[N] if ref.shape[0] >= N + 1 else ref[-1]
+        q[2 * N:2 * N + 2] = -c.Q @ r
+    q[c.n_x:] = c.grad_sub @ np.asarray(u_prev, float)
+    return q
+
+
+def mpc_assemble(c: MPCConstants, x0, ref, u_prev, hull_A, hull_b,
+                 q_prev=None, reset=True):
+    """(P, q, A, l, u) exactly as handed to OSQP.
+    A: WM/src/MPCSolver.cpp:76-123 (hull block at row 2(N+1), col 2(N+1) = u0 only);
+    l,u: :125-181 and ctor :43-49."""
+    hull_A = np.asarray(hull_A, float).reshape(-1, 2)
+    hull_b = np.asarray(hull_b, float).reshape(-1)
+    nc = hull_A.shape[0]
+    m = c.n_x + nc
+    A = np.zeros((m, c.n))
+    A[:c.n_x] = c.A_eq
+    A[c.n_x:, c.n_x:c.n_x + 2] = hull_A
+    l = np.zeros(m)
+    u = np.zeros(m)
+    l[0:2] = u[0:2] = -np.asarray(x0, float)
+    l[c.n_x:] = -OSQP_INFTY
+    u[c.n_x:] = hull_b
+    q = mpc_gradient(c, ref, u_prev, q_prev, reset)
+    return c.P, q, A, l, u
+
+
+def hull_margin(hull_A, hull_b, u) -> float:
+    """Signed distance of u from the polygon boundary, positive inside
+    (iDynTree ConvexHullProjectionConstraint::computeMargin semantics, upstream;
+    used at WM/src/WalkingDCMModelPredictiveController.cpp:513)."""
+    hull_A = np.asarray(hull_A, float).reshape(-1, 2)
+    hull_b = np.asarray(hull_b, float).reshape(-1)
+    nrm = np.linalg.norm(hull_A, axis=1)
+    ok = nrm > 0
+    if not ok.any():
+        return float("inf")
+    return float(np.min((hull_b[ok] - hull_A[ok] @ np.asarray(u, float)) / nrm[ok]))
+
+
+# --------------------------------------------------------------------------------------
+# Generic exact convex QP:  min 1/2 x'Hx + g'x  s.t.  Aeq x = beq,  Ain x <= bin
+# --------------------------------------------------------------------------------------
+class QPOracleError(RuntimeError):
+    pass
+
+
+def _kkt_solve(H, g, C, d):
+    n = H.shape[0]
+    k = C.shape[0]
+    K = np.zeros((n + k, n + k))
+    K[:n, :n] = H
+    K[:n, n:] = C.T
+    K[n:, :n] = C
+    rhs = np.concatenate([-g, d])
+    try:
+        sol = np.linalg.solve(K, rhs)
+    except np.linalg.LinAlgError:
+        sol = np.linalg.lstsq(K, rhs, rcond=None)[0]
+    return sol[:n], sol[n:]
+
+
+class QPInfeasible(QPOracleError):
+    pass
+
+
+def qp_feasible(Aeq, beq, Ain, bin_) -> bool:
+    """Phase-1 feasibility of {Aeq x = beq, Ain x <= bin} (scipy HiGHS LP)."""
+    from scipy.optimize import linprog
+    n = Aeq.shape[1] if Aeq.size else Ain.shape[1]
+    res = linprog(np.zeros(n), A_ub=Ain if Ain.size else None, b_ub=bin_ if Ain.size else None,
+                  A_eq=Aeq if Aeq.size else None, b_eq=beq if Aeq.size else None,
+                  bounds=[(None, None)] * n, method="highs")
+    return res.status == 0
+
+
+def _walk(H, g, Aeq, beq, Ain, bin_, scale, tol, max_iter, w0):
+    """add-most-violated / drop-most-negative walk over dense KKT solves."""
+    meq = Aeq.shape[0]
+    W = list(w0)
+    seen = set()
+    for _ in range(max_iter):
+        C = np.vstack([Aeq, Ain[W]]) if W else Aeq
+        d = np.concatenate([beq, bin_[W]]) if W else beq
+        x, lam = _kkt_solve(H, g, C, d)
+        mu_w = lam[meq:]
+        viol = (Ain @ x - bin_) / scale if Ain.size else np.zeros(0)
+        if W:
+            viol[W] = -np.inf
+        j = int(np.argmax(viol)) if viol.size else -1
+        if j >= 0 and viol[j] > tol:
+            W.append(j)
+        elif len(W) and mu_w.min() < -tol:
+            W.pop(int(np.argmin(mu_w)))
+        else:
+            return x, lam[:meq], mu_w, W
+        key = tuple(sorted(W))
+        if key in seen:
+            return None
+        seen.add(key)
+    return None
+
+
+def _goldfarb_idnani(H, g, Aeq, beq, Ain, bin_, tol, max_iter):
+    """Dual active set (Goldfarb & Idnani 1983) on M = H + Aeq'Aeq, equalities
+    eliminated through the projected inverse.  Fallback of qp_exact."""
+    n = H.shape[0]
+    M = H + Aeq.T @ Aeq
+    gt = g - Aeq.T @ beq
+    Minv = np.linalg.inv(M)
+    if Aeq.shape[0]:
+        G = Minv @ Aeq.T
+        Sinv = np.linalg.inv(Aeq @ G)
+        P = Minv - G @ Sinv @ G.T
+        lam = -Sinv @ (G.T @ gt + beq)
+        x = -Minv @ gt - G @ lam
+    else:
+        P = Minv
+        x = -Minv @ gt
+    W, mu, T = [], [], []
+    for _ in range(max_iter):
+        viol = Ain @ x - bin_
+        for w in W:
+            viol[w] = -np.inf
+        p = int(np.argmax(viol))
+        s = viol[p]
+        if s <= tol:
+            return x, W, mu
+        npv = Ain[p]
+        tp = P @ npv
+        mu_p = 0.0
+        while True:
+            k = len(W)
+            if k:
+                R = np.array([[Ain[W[a]] @ T[b] for b in range(k)] for a in range(k)])
+                c = np.array([Ain[W[a]] @ tp for a in range(k)])
+                r = np.linalg.solve(R, c)
+                z = tp - sum(r[a] * T[a] for a in range(k))
+            else:
+                r = np.zeros(0)
+                z = tp
+            nz = npv @ z
+            t2 = s / nz if nz > 1e-13 * max(1.0, npv @ tp) else np.inf
+            t1, jd = np.inf, -1
+            for a in range(k):
+                if r[a] > 0 and mu[a] / r[a] < t1:
+                    t1, jd = mu[a] / r[a], a
+            t = min(t1, t2)
+            if not np.isfinite(t):
+                raise QPInfeasible("dual unbounded")
+            x = x - t * z
+            for a in range(k):
+                mu[a] -= t * r[a]
+            mu_p += t
+            s -= t * nz
+            if t2 <= t1:
+                W.append(p); mu.append(mu_p); T.append(tp)
+                break
+            W.pop(jd); mu.pop(jd); T.pop(jd)
+    raise QPOracleError("Goldfarb-Idnani did not terminate")
+
+
+def qp_exact(H, g, Aeq, beq, Ain, bin_, tol=1e-11, max_iter=200, w0: Sequence[int] = ()):
+    """Exact optimum of  min 1/2 x'Hx + g'x  s.t.  Aeq x = beq, Ain x <= bin.
+
+    An add-most-violated / drop-most-negative active-set walk over dense KKT solves
+    (a Goldfarb-Idnani dual method if the walk cycles), followed by an explicit KKT
+    CERTIFICATE: whatever produced the point, a returned point satisfies
+    stationarity, primal and dual feasibility and complementarity, hence is the
+    optimum.  Raises QPInfeasible / QPOracleError otherwise.
+
+    returns x, lam_eq, mu (len(Ain), >= 0), active (sorted index list)"""
+    H = np.asarray(H, float)
+    g = np.asarray(g, float)
+    Aeq = np.asarray(Aeq, float).reshape(-1, H.shape[0])
+    Ain = np.asarray(Ain, float).reshape(-1, H.shape[0])
+    beq = np.asarray(beq, float).reshape(-1)
+    bin_ = np.asarray(bin_, float).reshape(-1)
+    meq = Aeq.shape[0]
+    scale = np.maximum(1.0, np.linalg.norm(Ain, axis=1)) if Ain.size else np.ones(0)
+    out = _walk(H, g, Aeq, beq, Ain, bin_, scale, tol, max_iter, w0)
+    if out is None:
+        if not qp_feasible(Aeq, beq, Ain, bin_):
+            raise QPInfeasible("constraints admit no point")
+        x, W, _ = _goldfarb_idnani(H, g, Aeq, beq, Ain, bin_, tol, max_iter)
+        C = np.vstack([Aeq, Ain[W]]) if W else Aeq
+        d = np.concatenate([beq, bin_[W]]) if W else beq
+        x, lam = _kkt_solve(H, g, C, d)          # polish on the identified set
+        lam_eq, mu_w = lam[:meq], lam[meq:]
+    else:
+        x, lam_eq, mu_w, W = out
+    mu = np.zeros(Ain.shape[0])
+    if W:
+        mu[W] = mu_w
+    # ---- KKT certificate -----------------------------------------------------------
+    gs = max(1.0, np.abs(g).max(), np.abs(H @ x).max())
+    stat = H @ x + g + Aeq.T @ lam_eq + (Ain.T @ mu if Ain.size else 0.0)
+    if np.abs(stat).max() > 1e-7 * gs:
+        raise QPOracleError(f"stationarity residual {np.abs(stat).max():.3e}")
+    if meq and np.abs(Aeq @ x - beq).max() > 1e-8 * max(1.0, np.abs(beq).max()):
+        raise QPOracleError("equality residual")
+    if Ain.size:
+        if ((Ain @ x - bin_) / scale).max() > 1e-8:
+            if not qp_feasible(Aeq, beq, Ain, bin_):
+                raise QPInfeasible("constraints admit no point")
+            raise QPOracleError("primal infeasible")
+        if mu.min() < -1e-8 * gs:
+            raise QPOracleError("dual infeasible")
+    return x, lam_eq, mu, sorted(W)
+
+
+def mpc_exact(c: MPCConstants, x0, ref, u_prev, hull_A, hull_b, nc=None):
+    """Exact optimum of the MPC QP.  Returns dict(z, u0, active(list of hull rows),
+    mu (per hull row), gap): `gap` is the strict-complementarity margin
+    min( min_active mu_i / scale , min_inactive slack_i ) used to exclude ties."""
+    hull_A = np.asarray(hull_A, float).reshape(-1, 2)
+    hull_b = np.asarray(hull_b, float).reshape(-1)
+    if nc is not None:
+        hull_A, hull_b = hull_A[:nc], hull_b[:nc]
+    P, q, A, l, u = mpc_assemble(c, x0, ref, u_prev, hull_A, hull_b)
+    Aeq, beq = A[:c.n_x], u[:c.n_x]
+    Ain, bin_ = A[c.n_x:], u[c.n_x:]
+    z, lam, mu, act = qp_exact(P, q, Aeq, beq, Ain, bin_)
+    slack = bin_ - Ain @ z
+    inact = [i for i in range(len(bin_)) if i not in act]
+    return dict(z=z, u0=z[c.n_x:c.n_x + 2].copy(), active=act, mu=mu,
+                mu_min_active=min([mu[i] for i in act], default=np.inf),
+                slack_min_inactive=min([slack[i] for i in inact], default=np.inf),
+                margin=hull_margin(hull_A, hull_b, z[c.n_x:c.n_x + 2]))
+
+
+# --------------------------------------------------------------------------------------
+# A.2  QP-IK  (WalkingQPIK base + _osqp / _qpOASES back-ends)
+# --------------------------------------------------------------------------------------
+ICUB_JOINT_REG_DEG = np.array([15, 0, 0,
+                               -7, 22, 11, 30,
+                               -7, 22, 11, 30,
+                               5.082, 0.406, -0.131, -45.249, -26.454, -0.351,
+                               5.082, 0.406, -0.131, -45.249, -26.454, -0.351], float)
+ICUB_JOINT_REG_WEIGHTS = np.array([1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2] + [1] * 12, float)
+
+
+@dataclasses.dataclass
+class IKParams:
+    """Values of CFG/qpInverseKinematics.ini:2-32 (iCubGazeboV2_5, 23 DoF)."""
+    dof: int = 23
+    use_com_as_constraint: bool = True
+    com_weight: np.ndarray = dataclasses.field(default_factory=lambda: 100.0 * np.eye(3))
+    neck_weight: np.ndarray = dataclasses.field(default_factory=lambda: 5.0 * np.eye(3))
+    additional_rotation: np.ndarray = dataclasses.field(
+        default_factory=lambda: np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]))
+    joint_reg_deg: np.ndarray = dataclasses.field(default_factory=lambda: ICUB_JOINT_REG_DEG.copy())
+    joint_reg_weights: np.ndarray = dataclasses.field(default_factory=lambda: ICUB_JOINT_REG_WEIGHTS.copy())
+    joint_reg_gains: np.ndarray = dataclasses.field(default_factory=lambda: 5.0 * np.ones(23))
+    k_pos_com: float = 1.0
+    k_pos_foot: float = 4.0
+    k_att_foot: float = 2.0
+    k_neck: float = 1.0
+    v_max: np.ndarray = dataclasses.field(default_factory=lambda: np.ones(23))  # robot-supplied at run time (B-19)
+
+    @property
+    def q_reg(self) -> np.ndarray:
+        # deg -> rad: WM/src/WalkingQPInverseKinematics_osqp.cpp:101-102, _qpOASES.cpp:102-103
+        return np.deg2rad(self.joint_reg_deg)
+
+
+def rot_error(R: np.ndarray, Rd: np.ndarray) -> np.ndarray:
+    """unskew( skewSymmetric(R * Rd^-1) ),  skewSymmetric(X) = 0.5 (X - X')
+    modules/Utilities/src/Utils.cpp:22-27; iDynTree::unskew (upstream) picks
+    (X[2,1], X[0,2], X[1,0])."""
+    E = np.asarray(R, float) @ np.asarray(Rd, float).T
+    S = 0.5 * (E - E.T)
+    return np.array([S[2, 1], S[0, 2], S[1, 0]])
+
+
+@dataclasses.dataclass
+class IKInputs:
+    """One robot's per-tick IK inputs, in the reference's own units/layouts
+    (WM/include/WalkingQPInverseKinematics.hpp:27-56)."""
+    J_left: np.ndarray        # 6 x n
+    J_right: np.ndarray       # 6 x n
+    J_neck: np.ndarray        # 3 x n  (rows 3..5 of the 6 x n neck Jacobian, base.cpp:214-215)
+    J_com: np.ndarray         # 3 x n
+    q: np.ndarray             # dof
+    p_left: np.ndarray        # actual left foot position
+    R_left: np.ndarray        # actual left foot rotation
+    p_right: np.ndarray
+    R_right: np.ndarray
+    pd_left: np.ndarray       # desired left foot position
+    Rd_left: np.ndarray
+    pd_right: np.ndarray
+    Rd_right: np.ndarray
+    R_neck: np.ndarray        # actual neck rotation
+    Rd_neck: np.ndarray       # desired neck rotation AFTER `* additional_rotation` (base.cpp:143-146)
+    com: np.ndarray           # actual CoM position
+    com_des: np.ndarray       # desired CoM position
+    com_vel_des: np.ndarray   # desired CoM velocity
+    twist_left: np.ndarray    # desired left foot twist (6)
+    twist_right: np.ndarray   # desired right foot twist (6)
+
+
+def ik_hessian(p: IKParams, x: IKInputs) -> np.ndarray:
+    """H = Lambda + Jn' Wn Jn (+ Jc' Wc Jc).
+    base.cpp:64-67 (Lambda = diag(0_6, w)); _osqp.cpp:142-151; _qpOASES.cpp:138-150."""
+    n = p.dof + 6
+    H = np.zeros((n, n))
+    H[np.arange(6, n), np.arange(6, n)] = p.joint_reg_weights
+    H += x.J_neck.T @ p.neck_weight @ x.J_neck
+    if not p.use_com_as_constraint:
+        H += x.J_com.T @ p.com_weight @ x.J_com
+    return H
+
+
+def ik_gradient(p: IKParams, x: IKInputs, form: str) -> np.ndarray:
+    """g.  form='osqp': extra k_attFoot factor on the neck term (_osqp.cpp:181-196);
+    form='qpoases': no such factor (_qpOASES.cpp:161-178)."""
+    n = p.dof + 6
+    kappa = p.k_att_foot if form == "osqp" else 1.0
+    e_neck = rot_error(x.R_neck, x.Rd_neck)
+    g = -x.J_neck.T @ p.neck_weight @ (kappa * (-p.k_neck * e_neck))
+    lam_g = np.zeros((n, p.dof))
+    lam_g[np.arange(6, n), np.arange(p.dof)] = p.joint_reg_weights         # base.cpp:70-72
+    g = g - lam_g @ (p.joint_reg_gains * (p.q_reg - x.q))
+    if not p.use_com_as_constraint:
+        g = g - x.J_com.T @ p.com_weight @ x.com_vel_des
+    return g
+
+
+def ik_task_rhs(p: IKParams, x: IKInputs, form: str) -> np.ndarray:
+    """Right-hand side of the task equality rows (l = u).
+    _osqp.cpp:266-313 (zero-twist special case :286-306);
+    _qpOASES.cpp:216-279 (always corrected :249-271)."""
+    cl = np.concatenate([p.k_pos_foot * (x.p_left - x.pd_left),
+                         p.k_att_foot * rot_error(x.R_left, x.Rd_left)])
+    cr = np.concatenate([p.k_pos_foot * (x.p_right - x.pd_right),
+                         p.k_att_foot * rot_error(x.R_right, x.Rd_right)])
+    tl, tr = np.asarray(x.twist_left, float), np.asarray(x.twist_right, float)
+    if form == "osqp" and tl[0] == tl[1] and tl[0] == 0:
+        bl = tl.copy()
+    else:
+        bl = tl - cl
+    if form == "osqp" and tr[0] == tr[1] and tr[0] == 0:
+        br = tr.copy()
+    else:
+        br = tr - cr
+    rows = [bl, br]
+    if p.use_com_as_constraint:
+        rows.append(x.com_vel_des - p.k_pos_com * (x.com - x.com_des))
+    return np.concatenate(rows)
+
+
+def ik_task_matrix(p: IKParams, x: IKInputs) -> np.ndarray:
+    """[J_L; J_R; (J_c)].  _osqp.cpp:218-236, _qpOASES.cpp:184-214."""
+    rows = [x.J_left, x.J_right]
+    if p.use_com_as_constraint:
+        rows.append(x.J_com)
+    return np.vstack(rows)
+
+
+def ik_assemble_osqp(p: IKParams, x: IKInputs):
+    """(P, q, A, l, u) handed to OSQP by WalkingQPIK_osqp: m = dof + 12 (+3).
+    The joint-limit selector triplets are never populated (_osqp.hpp:18,
+    _osqp.cpp:227-235), so the last `dof` rows of A are ZERO and the bounds
+    -v_max <= 0 <= v_max never bind."""
+    n = p.dof + 6
+    At = ik_task_matrix(p, x)
+    nt = At.shape[0]
+    A = np.zeros((nt + p.dof, n))
+    A[:nt] = At
+    b = ik_task_rhs(p, x, "osqp")
+    l = np.concatenate([b, -p.v_max])       # _osqp.cpp:45-49
+    u = np.concatenate([b, +p.v_max])
+    return ik_hessian(p, x), ik_gradient(p, x, "osqp"), A, l, u
+
+
+def ik_assemble_qpoases(p: IKParams, x: IKInputs):
+    """(H, g, A, lb, ub, lbA, ubA) handed to qpOASES::SQProblem::init/hotstart
+    (_qpOASES.cpp:284-339).  Base bounds are +-DBL_MAX (:39-43)."""
+    b = ik_task_rhs(p, x, "qpoases")
+    big = np.finfo(float).max
+    lb = np.concatenate([-big * np.ones(6), -p.v_max])
+    ub = np.concatenate([+big * np.ones(6), +p.v_max])
+    return ik_hessian(p, x), ik_gradient(p, x, "qpoases"), ik_task_matrix(p, x), lb, ub, b, b.copy()
+
+
+def ik_exact(p: IKParams, x: IKInputs, form: str):
+    """Exact optimum.  form='qpoases': bounds enforced; form='osqp': no bounds
+    (zero rows).  Returns dict(nu, dq, lower(list), upper(list), mu_lo, mu_up,
+    mu_min_active, slack_min_inactive, foot_err_left, foot_err_right)."""
+    H = ik_hessian(p, x)
+    g = ik_gradient(p, x, form)
+    A = ik_task_matrix(p, x)
+    b = ik_task_rhs(p, x, form)
+    n = p.dof + 6
+    if form == "qpoases":
+        E = np.zeros((p.dof, n))
+        E[np.arange(p.dof), np.arange(6, n)] = 1.0
+        Ain = np.vstack([E, -E])
+        bin_ = np.concatenate([p.v_max, p.v_max])
+    else:
+        Ain = np.zeros((0, n))
+        bin_ = np.zeros(0)
+    nu, lam, mu, act = qp_exact(H, g, A, b, Ain, bin_)
+    upper = [i for i in act if i < p.dof]
+    lower = [i - p.dof for i in act if i >= p.dof]
+    slack = bin_ - Ain @ nu if Ain.size else np.zeros(0)
+    inact = [i for i in range(len(bin_)) if i not in act]
+    return dict(nu=nu, dq=nu[6:].copy(), lower=lower, upper=upper, lam=lam,
+                mu_up=mu[:p.dof] if Ain.size else np.zeros(p.dof),
+                mu_lo=mu[p.dof:] if Ain.size else np.zeros(p.dof),
+                mu_min_active=min([mu[i] for i in act], default=np.inf),
+                slack_min_inactive=min([slack[i] for i in inact], default=np.inf),
+                # "errors" = (v* - c) - J nu  (_osqp.cpp:439,452; _qpOASES.cpp:376-399)
+                foot_err_left=b[0:6] - x.J_left @ nu,
+                foot_err_right=b[6:12] - x.J_right @ nu)
+
+
+# --------------------------------------------------------------------------------------
+# adapters from the C-ABI batch layout (include/wcqp.h, walking-controllers_amd/synth.py)
+# --------------------------------------------------------------------------------------
+IK_STATE_OFFSETS = dict(
+    p_left=0, R_left=3, p_right=12, R_right=15,
+    pd_left=24, Rd_left=27, pd_right=36, Rd_right=39,
+    R_neck=48, Rd_neck=57,
+    com=66, com_des=69, com_vel_des=72,
+    twist_left=75, twist_right=81,
+)
+
+
+def ik_inputs_from_batch(batch: dict, i: int) -> IKInputs:
+    s = batch["state"][i]
+    o = IK_STATE_OFFSETS
+
+    def v(name, k):
+        return s[o[name]:o[name] + k].copy()
+
+    def m(name):
+        return s[o[name]:o[name] + 9].reshape(3, 3).copy()
+
+    return IKInputs(
+        J_left=batch["J_left"][i], J_right=batch["J_right"][i],
+        J_neck=batch["J_neck"][i], J_com=batch["J_com"][i], q=batch["q"][i],
+        p_left=v("p_left", 3), R_left=m("R_left"), p_right=v("p_right", 3), R_right=m("R_right"),
+        pd_left=v("pd_left", 3), Rd_left=m("Rd_left"), pd_right=v("pd_right", 3), Rd_right=m("Rd_right"),
+        R_neck=m("R_neck"), Rd_neck=m("Rd_neck"),
+        com=v("com", 3), com_des=v("com_des", 3), com_vel_des=v("com_vel_des", 3),
+        twist_left=v("twist_left", 6), twist_right=v("twist_right", 6))

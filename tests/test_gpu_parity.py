@@ -1,0 +1,213 @@
+"""
+GPU parity tests: the HIP path, called through the C ABI (libwcqp.so), against
+  * the committed golden vectors (exact fp64 optimum from oracle/qp_spec.py), and
+  * the oracle run here on the same seeded inputs at sizes it finishes in seconds, and
+  * size-independent KKT properties at BASELINE.json's full batch sizes.
+
+Tolerances (fp64 path; north_star: "solutions within 1e-6 of reference, active-set
+indices bit-exact"):
+  |x_gpu - x_exact|_inf <= 1e-9 (three orders tighter than required);
+  active sets compared bit-for-bit on instances whose strict-complementarity margin
+  (smallest active multiplier / smallest inactive slack) exceeds 1e-7; ties are counted
+  and must stay rare.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SOL_TOL = 1e-9
+MARGIN = 1e-7
+
+
+def _load(golden_dir, name):
+    import os
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _clear_cut(g):
+    return (g["mu_min_active"] > MARGIN) & (g["slack_min_inactive"] > MARGIN)
+
+
+# ------------------------------------------------------------------------------- MPC ---
+@pytest.mark.parametrize("name,kw", [("mpc_cfg2_b4096.npz", {}),
+                                     ("mpc_stress_b1024.npz", {"uprev_sigma": 0.04})])
+def test_mpc_matches_golden(wca, golden_dir, name, kw):
+    g = _load(golden_dir, name)
+    B, seed = int(g["count"]), int(g["seed"])
+    b = wca.synth.synth_mpc_batch(B, seed=seed, **kw)
+    assert np.array_equal(b["ref"][:4], g["in_ref"]) and np.array_equal(b["hull_b"][:4], g["in_hull_b"])
+    out = wca.MpcSolver().solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    assert (out["status"] == wca.STATUS_SOLVED).all()
+    assert np.abs(out["u0"] - g["u0"]).max() <= SOL_TOL
+    cc = _clear_cut(g)
+    assert cc.mean() > 0.98
+    assert np.array_equal(out["active"][cc], g["active"][cc])          # bit-exact active sets
+    assert np.abs(out["margin"] - g["margin"]).max() <= 1e-9
+
+
+def test_mpc_against_oracle_live(wca, qs):
+    """Fresh seeds, wider disturbances, every contact configuration."""
+    c = qs.mpc_constants(qs.MPCParams())
+    B = 192
+    b = wca.synth.synth_mpc_batch(B, seed=2024, uprev_sigma=0.06, x0_sigma=0.03)
+    out = wca.MpcSolver().solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    nact = 0
+    for i in range(B):
+        r = qs.mpc_exact(c, b["x0"][i], b["ref"][i], b["u_prev"][i], b["hull_A"][i], b["hull_b"][i], int(b["hull_nc"][i]))
+        assert np.abs(out["u0"][i] - r["u0"]).max() <= SOL_TOL
+        if r["mu_min_active"] > MARGIN and r["slack_min_inactive"] > MARGIN:
+            assert int(out["active"][i]) == sum(1 << e for e in r["active"])
+        nact += len(r["active"])
+    assert nact > B // 2          # the hull really binds in this variant
+
+
+def test_mpc_short_reference_is_padded(wca, qs):
+    """ref_len < N+1: the tail repeats the last sample (MPCSolver.cpp:200-214)."""
+    c = qs.mpc_constants(qs.MPCParams())
+    b = wca.synth.synth_mpc_batch(16, seed=5, uprev_sigma=0.03)
+    short = np.ascontiguousarray(b["ref"][:, :7, :])
+    out = wca.MpcSolver().solve_host(b["x0"], short, b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    for i in range(16):
+        r = qs.mpc_exact(c, b["x0"][i], short[i], b["u_prev"][i], b["hull_A"][i], b["hull_b"][i], int(b["hull_nc"][i]))
+        assert np.abs(out["u0"][i] - r["u0"]).max() <= SOL_TOL
+
+
+def test_mpc_edge_cases(wca, qs):
+    c = qs.mpc_constants(qs.MPCParams())
+    m = wca.MpcSolver()
+    b = wca.synth.synth_mpc_batch(5, seed=9, uprev_sigma=0.08)       # odd batch: ragged last wave
+    # (a) no hull rows at all -> unconstrained optimum
+    nc0 = np.zeros(5, np.int32)
+    out = m.solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], nc0)
+    for i in range(5):
+        r = qs.mpc_exact(c, b["x0"][i], b["ref"][i], b["u_prev"][i], np.zeros((0, 2)), np.zeros(0))
+        assert np.abs(out["u0"][i] - r["u0"]).max() <= SOL_TOL
+        assert out["active"][i] == 0 and np.isinf(out["margin"][i])
+    # (b) empty polygon -> INFEASIBLE, never a silent answer
+    A = b["hull_A"].copy(); bb = b["hull_b"].copy()
+    A[:, 0] = [1.0, 0.0]; bb[:, 0] = -1.0
+    A[:, 1] = [-1.0, 0.0]; bb[:, 1] = -1.0           # x <= -1 and x >= 1
+    out = m.solve_host(b["x0"], b["ref"], b["u_prev"], A, bb, b["hull_nc"])
+    assert (out["status"] == wca.STATUS_INFEASIBLE).all()
+    # (c) batch of one == per-robot call
+    one = m.solve_host(b["x0"][:1], b["ref"][:1], b["u_prev"][:1], b["hull_A"][:1], b["hull_b"][:1], b["hull_nc"][:1])
+    full = m.solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    assert np.array_equal(one["u0"][0], full["u0"][0])
+
+
+def test_mpc_properties_at_full_size(wca):
+    """BASELINE config 4 per-GPU size (8192): feasibility, idempotence, permutation invariance."""
+    B = 8192
+    b = wca.synth.synth_mpc_batch(B, seed=31, uprev_sigma=0.05)
+    m = wca.MpcSolver()
+    out = m.solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    assert (out["status"] == wca.STATUS_SOLVED).all()
+    res = np.einsum("bkc,bc->bk", b["hull_A"], out["u0"]) - b["hull_b"]
+    assert res.max() <= 1e-10                               # inside the polygon
+    act = out["active"]
+    for e in range(8):                                      # active rows are tight
+        on = (act >> e) & 1 == 1
+        assert np.abs(res[on, e]).max(initial=0.0) <= 1e-12
+    perm = np.random.default_rng(0).permutation(B)
+    out2 = m.solve_host(b["x0"][perm], b["ref"][perm], b["u_prev"][perm], b["hull_A"][perm], b["hull_b"][perm], b["hull_nc"][perm])
+    assert np.array_equal(out2["u0"], out["u0"][perm])      # batch-permutation invariance, bitwise
+    assert np.array_equal(out2["active"], act[perm])
+
+
+# -------------------------------------------------------------------------------- IK ---
+def _ik_solver(wca, form, vmax):
+    return wca.IkSolver(form=wca.IK_FORM_QPOASES if form == "qpoases" else wca.IK_FORM_OSQP, v_max=vmax)
+
+
+@pytest.mark.parametrize("name", ["ik_qpoases_v050_b1024.npz", "ik_qpoases_v030_b512.npz", "ik_osqp_b512.npz"])
+def test_ik_matches_golden(wca, golden_dir, name):
+    g = _load(golden_dir, name)
+    B, seed, form, vmax = int(g["count"]), int(g["seed"]), str(g["form"]), float(g["v_max"])
+    b = wca.synth.synth_ik_batch(B, seed=seed)
+    assert np.array_equal(b["J_left"][:2], g["in_J_left"]) and np.array_equal(b["state"][:2], g["in_state"])
+    out = _ik_solver(wca, form, vmax).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    ok = g["status"] == 0
+    assert (out["status"][ok] == wca.STATUS_SOLVED).all()
+    assert (out["status"][~ok] == wca.STATUS_INFEASIBLE).all()
+    assert np.abs(out["dq"][ok] - g["dq"][ok]).max() <= SOL_TOL
+    assert np.abs(out["foot_err"][ok] - g["foot_err"][ok]).max() <= 1e-8
+    cc = _clear_cut(g) & ok
+    assert cc.mean() > 0.97
+    assert np.array_equal(out["active_lower"][cc], g["active_lower"][cc])   # bit-exact active sets
+    assert np.array_equal(out["active_upper"][cc], g["active_upper"][cc])
+
+
+@pytest.mark.parametrize("form,vmax", [("qpoases", 0.4), ("qpoases", 0.22), ("osqp", 0.3)])
+def test_ik_against_oracle_live(wca, qs, form, vmax):
+    B = 160
+    b = wca.synth.synth_ik_batch(B, seed=99)
+    p = qs.IKParams(v_max=vmax * np.ones(23))
+    out = _ik_solver(wca, form, vmax).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    checked = 0
+    for i in range(B):
+        x = qs.ik_inputs_from_batch(b, i)
+        try:
+            r = qs.ik_exact(p, x, form)
+        except qs.QPInfeasible:
+            assert out["status"][i] == wca.STATUS_INFEASIBLE
+            continue
+        assert out["status"][i] == wca.STATUS_SOLVED
+        assert np.abs(out["dq"][i] - r["dq"]).max() <= SOL_TOL
+        if r["mu_min_active"] > MARGIN and r["slack_min_inactive"] > MARGIN:
+            assert int(out["active_lower"][i]) == sum(1 << j for j in r["lower"])
+            assert int(out["active_upper"][i]) == sum(1 << j for j in r["upper"])
+        checked += 1
+    assert checked > B * 0.8
+
+
+def test_ik_osqp_form_quirks(wca, qs):
+    """osqp back-end: limits never bind, extra k_attFoot on the neck term, zero-twist rule
+    (SURVEY Appendix B-13/14/15): the two forms must DIFFER on the same inputs."""
+    b = wca.synth.synth_ik_batch(32, seed=3)
+    a = _ik_solver(wca, "osqp", 0.2).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    q = _ik_solver(wca, "qpoases", 0.2).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    assert (a["active_lower"] == 0).all() and (a["active_upper"] == 0).all()
+    assert np.abs(a["dq"]).max() > 0.2 + 1e-3            # limits are NOT enforced in this form
+    ok = q["status"] == wca.STATUS_SOLVED
+    assert np.abs(q["dq"][ok]).max() <= 0.2 + 1e-12
+    assert np.abs(a["dq"] - q["dq"]).max() > 1e-3
+
+
+def test_ik_com_as_cost_variant(wca, qs):
+    """useCoMAsConstraint = 0: 12 equality rows, CoM task moves into the cost."""
+    B = 48
+    b = wca.synth.synth_ik_batch(B, seed=17)
+    p = qs.IKParams(use_com_as_constraint=False, v_max=0.4 * np.ones(23))
+    s = wca.IkSolver(form=wca.IK_FORM_QPOASES, use_com_as_constraint=False, v_max=0.4)
+    out = s.solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    for i in range(B):
+        r = qs.ik_exact(p, qs.ik_inputs_from_batch(b, i), "qpoases")
+        assert out["status"][i] == wca.STATUS_SOLVED
+        assert np.abs(out["dq"][i] - r["dq"]).max() <= SOL_TOL
+
+
+def test_ik_properties_at_full_size(wca):
+    """BASELINE config 3 size (4096) + ragged batch: KKT-type properties computed here in
+    numpy from the GPU output alone, plus permutation invariance."""
+    B = 4097
+    vmax = 0.5
+    b = wca.synth.synth_ik_batch(B, seed=8)
+    s = _ik_solver(wca, "qpoases", vmax)
+    out = s.solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    ok = out["status"] == wca.STATUS_SOLVED
+    assert ok.mean() > 0.999
+    dq = out["dq"]
+    assert np.abs(dq[ok]).max() <= vmax + 1e-12                          # bounds hold
+    lo, up = out["active_lower"], out["active_upper"]
+    for j in range(23):                                                  # active bounds are tight
+        assert np.abs(dq[ok & ((up >> j) & 1 == 1), j] - vmax).max(initial=0.0) <= 1e-12
+        assert np.abs(dq[ok & ((lo >> j) & 1 == 1), j] + vmax).max(initial=0.0) <= 1e-12
+    assert (lo & up == 0).all()
+    # equality rows: J nu = b  <=>  reported foot errors vanish (they are b - J nu)
+    assert np.abs(out["foot_err"][ok]).max() <= 1e-9
+    perm = np.random.default_rng(1).permutation(B)
+    out2 = s.solve_host(b["J_left"][perm], b["J_right"][perm], b["J_neck"][perm], b["J_com"][perm],
+                        b["q"][perm], b["state"][perm])
+    assert np.array_equal(out2["dq"], dq[perm])                          # bitwise, whatever the lane half
+    assert np.array_equal(out2["active_upper"], up[perm])

@@ -1,0 +1,87 @@
+// Host-side helpers shared by libwcqp's translation units.
+#include <cmath>
+#include "wcqp_internal.h"
+
+namespace wcqp {
+
+bool lu_factor(std::vector<double>& a, int n, std::vector<int>& piv) {
+    piv.resize(n);
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = std::fabs(a[(size_t)k * n + k]);
+        for (int r = k + 1; r < n; ++r) {
+            const double v = std::fabs(a[(size_t)r * n + k]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (!(best > 0.0)) return false;
+        piv[k] = p;
+        if (p != k)
+            for (int c = 0; c < n; ++c) std::swap(a[(size_t)k * n + c], a[(size_t)p * n + c]);
+        const double inv = 1.0 / a[(size_t)k * n + k];
+        for (int r = k + 1; r < n; ++r) {
+            const double f = a[(size_t)r * n + k] * inv;
+            a[(size_t)r * n + k] = f;
+            if (f == 0.0) continue;
+            const double* src = &a[(size_t)k * n];
+            double* dst = &a[(size_t)r * n];
+            for (int c = k + 1; c < n; ++c) dst[c] -= f * src[c];
+        }
+    }
+    return true;
+}
+
+void lu_solve(const std::vector<double>& lu, const std::vector<int>& piv, int n, double* b) {
+    // rows were swapped whole (LAPACK getrf convention): permute b completely first
+    for (int k = 0; k < n; ++k)
+        if (piv[k] != k) std::swap(b[k], b[piv[k]]);
+    for (int k = 0; k < n; ++k) {
+        const double bk = b[k];
+        if (bk != 0.0)
+            for (int r = k + 1; r < n; ++r) b[r] -= lu[(size_t)r * n + k] * bk;
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        double s = b[k];
+        for (int c = k + 1; c < n; ++c) s -= lu[(size_t)k * n + c] * b[c];
+        b[k] = s / lu[(size_t)k * n + k];
+    }
+}
+
+int DeviceScratch::reserve(size_t bytes) {
+    if (bytes <= cap) return WCQP_OK;
+    if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+    if (hipMalloc(&ptr, bytes) != hipSuccess) { ptr = nullptr; return WCQP_E_NOMEM; }
+    cap = bytes;
+    return WCQP_OK;
+}
+
+void DeviceScratch::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+}  // namespace wcqp
+
+extern "C" {
+
+const char* wcqp_strerror(int code) {
+    switch (code) {
+        case WCQP_OK: return "ok";
+        case WCQP_E_INVALID: return "invalid argument";
+        case WCQP_E_UNSUPPORTED: return "unsupported problem size";
+        case WCQP_E_NUMERIC: return "constant precomputation failed (singular KKT)";
+        case WCQP_E_HIP: return "HIP runtime error or no device (this path has no CPU fallback)";
+        case WCQP_E_NOMEM: return "out of memory";
+        default: return "unknown wcqp error";
+    }
+}
+
+int wcqp_version(void) { return WCQP_VERSION; }
+
+int wcqp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,625 @@
+// Jacobian QP-IK: one HIP kernel, 32 lanes per robot instance (two instances per wave64).
+//
+// Reference path replaced (citations relative to /root/reference/modules/Walking_module):
+//   constants  WalkingQPIK::initializeMatrices          src/WalkingQPInverseKinematics.cpp:25-116
+//   per tick   WalkingQPIK_osqp::{setHessianMatrix,setGradientVector,setLinearConstraintMatrix,
+//              setBounds,solve,getSolution,get*FootError} src/WalkingQPInverseKinematics_osqp.cpp:135-454
+//              WalkingQPIK_qpOASES::{same}               src/WalkingQPInverseKinematics_qpOASES.cpp:135-401
+//
+// QP, nu = [v_base(6); dq(dof)], n = dof + 6 = 29:
+//      min 1/2 nu'H nu + g'nu   s.t.  A nu = b,   v_min <= dq <= v_max (qpOASES form only)
+//      H = Lambda + Jn'Wn Jn (+ Jc'Wc Jc)  is only PSD (rank 26/29), so the kernel works on
+//      M = H + rho A'A  (PD whenever the KKT matrix is regular; identical optimum and
+//      identical multipliers because A nu = b holds at every iterate).
+//
+// Layout: lane i of a 32-lane group owns variable i: row i of the symmetric matrices lives
+// in its REGISTERS (static indices, fully unrolled), and the only cross-lane traffic is one
+// published column per elimination step, written to LDS once and read back as a broadcast.
+//   1. M rows        M[i][:] = Lambda_i e_i + sum_r Cl[r][i] * Cr[r][:]     (18 stacked task rows)
+//   2. Minv          symmetric sweep operator over the 29 pivots
+//   3. G+ = Minv [A' g~],  S+ = [A; g~'] G+,  Sinv by a second sweep (15 pivots)
+//   4. equality optimum  lambda = -Sinv (A Minv g~ + b),  nu = -Minv g~ - G lambda
+//   5. bounds        Goldfarb-Idnani dual active set expressed through columns of the
+//                    projected inverse  P = Minv - G Sinv G'  (no refactorisation per change)
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include "wcqp_internal.h"
+
+namespace {
+
+constexpr int kDof = 23;
+constexpr int kNV = kDof + 6;          // 29
+constexpr int kLD = 30;                // leading dim of 29-wide LDS rows: even (16-B aligned b128
+                                       // broadcasts) and 60 dwords mod 64 -> at most 2-way on row-per-lane reads
+constexpr int kLDG = 18;               // leading dim of G+ rows (<= 16 columns)
+constexpr int kRows = 18;              // stacked task rows: J_left 6 | J_right 6 | J_com 3 | J_neck 3
+constexpr int kStateLen = WCQP_IK_STATE_LEN;
+
+struct IkDeviceParams {
+    double lam[32];        // Lambda diagonal per variable (0 on the base)       base.cpp:64-67
+    double kq[32];         // w_i * K_i per variable                              base.cpp:70-72,87-89
+    double qreg[32];       // regularisation posture per variable (rad)
+    double vlo[32], vhi[32];   // variable bounds; base = -/+ DBL_MAX            qp.cpp:39-49
+    double Wn[9], Wc[9];
+    double k_pos_com, k_pos_foot, k_att_foot, k_neck, kappa, rho, tol;
+    int form, max_iter;
+};
+
+template <bool USE_COM>
+struct IkLayout {
+    static constexpr int MEQ = USE_COM ? 15 : 12;       // equality rows
+    static constexpr int NC1 = MEQ + 1;                 // columns of G+ = [A' g~]
+    static constexpr int KMAX = kNV - MEQ;              // most bounds that can be active at once
+    static constexpr int LDS_S = 16;                    // leading dim of Sinv rows
+    static constexpr int LDL = KMAX + 1;
+    // ---- per-instance LDS map (doubles) ----
+    static constexpr int OFF_CR = 0;                    // [18][kLD]   phases 1-5
+    static constexpr int OFF_GM = OFF_CR + kRows * kLD; // [29][kLDG]  phases 4-5
+    static constexpr int END_MAT = OFF_GM + kNV * kLDG;
+    // phase 6 reuses the matrix area
+    static constexpr int OFF_TC = 0;                    // [KMAX][32]
+    static constexpr int OFF_SV = OFF_TC + KMAX * 32;   // [MEQ][LDS_S]
+    static constexpr int OFF_LK = OFF_SV + MEQ * LDS_S; // [KMAX][LDL]
+    static constexpr int END_AS = OFF_LK + KMAX * LDL;
+    static_assert(END_AS <= END_MAT, "active-set scratch must fit in the dead matrix area");
+    static constexpr int OFF_ST = END_MAT;              // [112] state 87 + q 23; later 4 x [32] vectors
+    static constexpr int OFF_V0 = OFF_ST;               // vbuf   (violations)
+    static constexpr int OFF_V1 = OFF_ST + 32;          // sgbuf / zbuf
+    static constexpr int OFF_V2 = OFF_ST + 64;          // tpbuf
+    static constexpr int OFF_V3 = OFF_ST + 96;          // rowbuf [32]
+    static constexpr int OFF_COL = OFF_ST + 128;        // [32] published column
+    static constexpr int OFF_B = OFF_COL + 32;          // [16] task rhs
+    static constexpr int OFF_LAM = OFF_B + 16;          // [16] multipliers / rhs
+    static constexpr int OFF_GROW = OFF_LAM + 16;       // [16] one row of G
+    static constexpr int OFF_R = OFF_GROW + 16;         // [20] dual step r
+    static constexpr int OFF_MU = OFF_R + 20;           // [20] multipliers of W
+    static constexpr int OFF_WS = OFF_MU + 20;          // [20] signs of W
+    static constexpr int OFF_WI = OFF_WS + 20;          // [20] ints (stored as doubles' space)
+    static constexpr int PER_INST = ((OFF_WI + 20) + 1) & ~1;
+};
+
+// rotation error component k of unskew(0.5 (E - E')), E = R Rd'     Utils.cpp:22-27
+__device__ __forceinline__ double rot_err(const double* R, const double* Rd, int k) {
+    const int a = (k + 2) % 3, b = (k + 1) % 3;
+    const double eab = R[3 * a] * Rd[3 * b] + R[3 * a + 1] * Rd[3 * b + 1] + R[3 * a + 2] * Rd[3 * b + 2];
+    const double eba = R[3 * b] * Rd[3 * a] + R[3 * b + 1] * Rd[3 * a + 1] + R[3 * b + 2] * Rd[3 * a + 2];
+    return 0.5 * (eab - eba);
+}
+
+// Symmetric sweep over pivots 0..SZ-1 of the matrix whose row i sits in `row` of lane i.
+// On exit row = -(A^-1) row.  Lanes >= SZ must hold zero rows (they act as padding).
+template <int SZ, int NR>
+__device__ __forceinline__ bool sweep_rows(double (&row)[NR], double* col, int i) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < SZ; ++k) {
+        const double ck = row[k];
+        col[i] = ck;                                   // column k == row k (symmetry)
+        wcqp::wave_lds_fence();
+        const double pk = col[k];
+        ok = ok && (pk > 0.0);
+        const double d = wcqp::fast_rcp(pk);
+        const double f0 = ck * d;
+        // lane k holds row k == the column itself: row - (1-d) col = d col, so one
+        // multiplier serves every lane and no per-element select is needed
+        const double f = (i == k) ? (1.0 - d) : f0;
+#pragma unroll
+        for (int j = 0; j < SZ; j += 2) {
+            const double2 c2 = *reinterpret_cast<const double2*>(col + j);
+            if (j != k) row[j] = fma(-f, c2.x, row[j]);
+            if (j + 1 < SZ && j + 1 != k) row[j + 1] = fma(-f, c2.y, row[j + 1]);
+        }
+        row[k] = (i == k) ? -d : f0;
+        wcqp::wave_lds_fence();
+    }
+    return ok;
+}
+
+template <bool USE_COM>
+__global__ __launch_bounds__(64, 2)
+void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
+               const double* __restrict__ JL, const double* __restrict__ JR,
+               const double* __restrict__ JN, const double* __restrict__ JC,
+               const double* __restrict__ qpos, const double* __restrict__ state,
+               double* __restrict__ dq_out, int* __restrict__ status_out,
+               unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
+               double* __restrict__ ferr_out, int* __restrict__ iters_out)
+{
+    using L = IkLayout<USE_COM>;
+    constexpr int MEQ = L::MEQ, NC1 = L::NC1, KMAX = L::KMAX;
+    __shared__ __attribute__((aligned(16))) double smem[2][L::PER_INST];
+
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    const int i = lane & 31;                       // variable owned by this lane
+    const long inst_raw = (long)blockIdx.x * 2 + half;
+    const bool live = inst_raw < batch;
+    const long inst = live ? inst_raw : (long)batch - 1;
+    double* S = smem[half];
+    double* Cr = S + L::OFF_CR;
+    double* Gm = S + L::OFF_GM;
+    double* st = S + L::OFF_ST;
+    double* col = S + L::OFF_COL;
+    double* bvec = S + L::OFF_B;
+    double* lamv = S + L::OFF_LAM;
+    const double inf = std::numeric_limits<double>::infinity();
+    const bool var = i < kNV;
+
+    // ---------------- phase 0: loads --------------------------------------------------
+    // column i of the stacked task Jacobian [J_left; J_right; J_com; J_neck]: consecutive
+    // lanes read consecutive doubles of each 29-wide row.
+    double cl[kRows];
+    {
+        const double* jl = JL + inst * (6 * kNV);
+        const double* jr = JR + inst * (6 * kNV);
+        const double* jc = JC + inst * (3 * kNV);
+        const double* jn = JN + inst * (3 * kNV);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) cl[r] = var ? jl[r * kNV + i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) cl[6 + r] = var ? jr[r * kNV + i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cl[12 + r] = var ? jc[r * kNV + i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cl[15 + r] = var ? jn[r * kNV + i] : 0.0;
+        const double* sp = state + inst * kStateLen;
+        st[i] = sp[i];
+        st[i + 32] = sp[i + 32];
+        if (i + 64 < kStateLen) st[i + 64] = sp[i + 64];
+        if (i < kDof) st[kStateLen + i] = qpos[inst * kDof + i];
+    }
+    // right operands of the M build: equality rows as they are, cost rows pre-multiplied by W
+    if (i < kLD) {
+#pragma unroll
+        for (int r = 0; r < MEQ; ++r) Cr[r * kLD + i] = cl[r];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            Cr[(15 + r) * kLD + i] = prm->Wn[3 * r] * cl[15] + prm->Wn[3 * r + 1] * cl[16] + prm->Wn[3 * r + 2] * cl[17];
+        if (!USE_COM) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                Cr[(12 + r) * kLD + i] = prm->Wc[3 * r] * cl[12] + prm->Wc[3 * r + 1] * cl[13] + prm->Wc[3 * r + 2] * cl[14];
+        }
+    }
+    wcqp::wave_lds_fence();
+
+    // ---------------- phase 1: task rhs b (lane r < MEQ) and gradient g~ ----------------
+    const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
+    double b_mine = 0.0;
+    if (i < MEQ) {
+        if (i < 12) {
+            const int foot = i / 6, k = i % 6;           // 0 = left, 1 = right
+            const double* p  = st + (foot ? 12 : 0);
+            const double* R  = st + (foot ? 15 : 3);
+            const double* pd = st + (foot ? 36 : 24);
+            const double* Rd = st + (foot ? 39 : 27);
+            const double* tw = st + (foot ? 81 : 75);
+            const double corr = k < 3 ? prm->k_pos_foot * (p[k] - pd[k]) : prm->k_att_foot * rot_err(R, Rd, k - 3);
+            // osqp back-end skips the correction when twist[0] == twist[1] == 0 (osqp.cpp:286-306)
+            const bool skip = osqp_form && tw[0] == tw[1] && tw[0] == 0.0;
+            b_mine = skip ? tw[k] : tw[k] - corr;
+        } else {
+            const int k = i - 12;                        // CoM rows (osqp.cpp:307-313, qp.cpp:273-279)
+            b_mine = st[72 + k] - prm->k_pos_com * (st[66 + k] - st[69 + k]);
+        }
+        bvec[i] = b_mine;
+    }
+    wcqp::wave_lds_fence();
+    double gt;   // g~_i = g_i - rho (A'b)_i
+    {
+        const double kap = prm->kappa * (-prm->k_neck);
+        const double e0 = kap * rot_err(st + 48, st + 57, 0);
+        const double e1 = kap * rot_err(st + 48, st + 57, 1);
+        const double e2 = kap * rot_err(st + 48, st + 57, 2);
+        // g = -Jn' Wn kappa(-k_neck e) - Lambda_g K (q_reg - q) [- Jc' Wc v_c]   osqp.cpp:181-196, qp.cpp:161-178
+        // Cr rows 15..17 hold (Wn Jn)[:, i] for this lane's column
+        double g = 0.0;
+        if (var) {
+            g = -(Cr[15 * kLD + i] * e0 + Cr[16 * kLD + i] * e1 + Cr[17 * kLD + i] * e2);
+            if (i >= 6) g -= prm->kq[i] * (prm->qreg[i] - st[kStateLen + i - 6]);
+            if (!USE_COM)
+                g -= Cr[12 * kLD + i] * st[72] + Cr[13 * kLD + i] * st[73] + Cr[14 * kLD + i] * st[74];
+        }
+        double atb = 0.0;
+#pragma unroll
+        for (int r = 0; r < MEQ; ++r) atb = fma(cl[r], bvec[r], atb);
+        gt = g - prm->rho * atb;
+    }
+
+    // ---------------- phase 2: M rows ---------------------------------------------------
+    double Mr[kNV];
+#pragma unroll
+    for (int j = 0; j < kNV; ++j) Mr[j] = 0.0;
+    {
+        const double rho = prm->rho;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const double own = (r < MEQ) ? rho * cl[r] : cl[r];
+#pragma unroll
+            for (int j = 0; j < kNV; j += 2) {
+                const double2 c2 = *reinterpret_cast<const double2*>(Cr + r * kLD + j);
+                Mr[j] = fma(own, c2.x, Mr[j]);
+                if (j + 1 < kNV) Mr[j + 1] = fma(own, c2.y, Mr[j + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every row's LDS reads
+        }
+        const double lam_i = prm->lam[i];
+#pragma unroll
+        for (int j = 0; j < kNV; ++j) Mr[j] += (i == j) ? lam_i : 0.0;
+    }
+
+    // ---------------- phase 3: Minv -----------------------------------------------------
+    bool ok = sweep_rows<kNV>(Mr, col, i);
+#pragma unroll
+    for (int j = 0; j < kNV; ++j) Mr[j] = -Mr[j];
+
+    // ---------------- phase 4: G+ = Minv [A' g~] ----------------------------------------
+    if (i < kLD) Cr[MEQ * kLD + i] = var ? gt : 0.0;     // row MEQ of C+ := g~ (cost rows are dead)
+    wcqp::wave_lds_fence();
+    double Gr[NC1];
+#pragma unroll
+    for (int c = 0; c < NC1; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < kNV; j += 2) {
+            const double2 c2 = *reinterpret_cast<const double2*>(Cr + c * kLD + j);
+            acc = fma(Mr[j], c2.x, acc);
+            if (j + 1 < kNV) acc = fma(Mr[j + 1], c2.y, acc);
+        }
+        Gr[c] = acc;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (var) {
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) Gm[i * kLDG + c] = Gr[c];
+    }
+    wcqp::wave_lds_fence();
+
+    // ---------------- phase 5: S+ rows, Sinv, lambda, equality optimum -------------------
+    double Sr[NC1];
+    {
+        const int cs = i <= MEQ ? i : MEQ;
+#pragma unroll
+        for (int d = 0; d < NC1; ++d) Sr[d] = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < kNV; ++k) {
+            const double a = Cr[cs * kLD + k];
+#pragma unroll
+            for (int d = 0; d < NC1; d += 2) {
+                const double2 g2 = *reinterpret_cast<const double2*>(Gm + k * kLDG + d);
+                Sr[d] = fma(a, g2.x, Sr[d]);
+                if (d + 1 < NC1) Sr[d + 1] = fma(a, g2.y, Sr[d + 1]);
+            }
+        }
+    }
+    // rhs_d = (A Minv g~)_d + b_d sits in lane d < MEQ
+    if (i < MEQ) lamv[i] = Sr[MEQ] + b_mine;
+    if (i >= MEQ) {
+#pragma unroll
+        for (int d = 0; d < NC1; ++d) Sr[d] = 0.0;
+    }
+    ok = sweep_rows<MEQ>(Sr, col, i) && ok;              // Sr = -Sinv rows on lanes < MEQ
+    {
+        double lam_c = 0.0;                              // lambda_c = -sum_d Sinv[c][d] rhs_d
+#pragma unroll
+        for (int d = 0; d < MEQ; ++d) lam_c = fma(Sr[d], lamv[d], lam_c);
+        wcqp::wave_lds_fence();
+        if (i < MEQ) lamv[i] = lam_c;
+        wcqp::wave_lds_fence();
+    }
+    double nu = -Gr[MEQ];
+#pragma unroll
+    for (int c = 0; c < MEQ; ++c) nu = fma(-Gr[c], lamv[c], nu);
+
+    // ---------------- phase 6: joint-velocity bounds (qpOASES form) ----------------------
+    int st_code = ok ? WCQP_STATUS_SOLVED : WCQP_STATUS_NUMERIC;
+    int it = 0;
+    bool in_w = false;
+    double my_sig = 0.0;
+    const double lo = var ? prm->vlo[i] : -inf, hi = var ? prm->vhi[i] : inf;
+    const double tol = prm->tol;
+    const bool need = !osqp_form && var && i >= 6 && fmax(nu - hi, lo - nu) > tol;
+    if (__ballot(need) != 0ull) {
+        double* Tc = S + L::OFF_TC;
+        double* Sv = S + L::OFF_SV;
+        double* Lk = S + L::OFF_LK;
+        double* vbuf = S + L::OFF_V0;
+        double* zbuf = S + L::OFF_V1;
+        double* tpb = S + L::OFF_V2;
+        double* rowbuf = S + L::OFF_V3;
+        double* grow = S + L::OFF_GROW;
+        double* rvec = S + L::OFF_R;
+        double* Wmu = S + L::OFF_MU;
+        double* Wsg = S + L::OFF_WS;
+        int* Wi = reinterpret_cast<int*>(S + L::OFF_WI);
+        // E = G Sinv (row i in registers): publish Sinv rows once
+        if (i < MEQ) {
+#pragma unroll
+            for (int d = 0; d < MEQ; ++d) Sv[i * L::LDS_S + d] = -Sr[d];
+        }
+        wcqp::wave_lds_fence();
+        double Er[MEQ];
+#pragma unroll
+        for (int c = 0; c < MEQ; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int d = 0; d < MEQ; ++d) acc = fma(Gr[d], Sv[d * L::LDS_S + c], acc);
+            Er[c] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        int nW = 0;
+        const int max_iter = prm->max_iter;
+        bool running = st_code == WCQP_STATUS_SOLVED;
+        while (running) {
+            // most violated bound outside W
+            const double v_hi = nu - hi, v_lo = lo - nu;
+            vbuf[i] = (var && i >= 6 && !in_w) ? fmax(v_hi, v_lo) : -inf;
+            zbuf[i] = v_hi >= v_lo ? 1.0 : -1.0;
+            wcqp::wave_lds_fence();
+            double s = -inf;
+            int p = 6;
+#pragma unroll 1
+            for (int j = 6; j < kNV; ++j) {
+                const double vj = vbuf[j];
+                if (vj > s) { s = vj; p = j; }
+            }
+            if (!(s > tol)) break;
+            if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; break; }
+            ++it;
+            const double sig = zbuf[p];
+            wcqp::wave_lds_fence();
+            // tp = sig * P[:, p],  P = Minv - E G'
+            if (i == p) {
+#pragma unroll
+                for (int j = 0; j < kNV; ++j) rowbuf[j] = Mr[j];
+#pragma unroll
+                for (int c = 0; c < MEQ; ++c) grow[c] = Gr[c];
+            }
+            wcqp::wave_lds_fence();
+            double tp = var ? rowbuf[i] : 0.0;
+#pragma unroll
+            for (int c = 0; c < MEQ; ++c) tp = fma(-Er[c], grow[c], tp);
+            tp *= sig;
+            double mu_p = 0.0;
+            tpb[i] = tp;
+            wcqp::wave_lds_fence();
+            const double ppp = sig * tpb[p];             // P[p][p] > 0
+#pragma unroll 1
+            for (int inner = 0; inner <= KMAX + 1; ++inner) {
+                // dual step r = R^-1 c,  R_ab = sig_a Tc[b][w_a],  c_a = sig_a tp[w_a]
+#pragma unroll 1
+                for (int a = 0; a < nW; ++a) {
+                    const int wa = Wi[a];
+                    const double sa = Wsg[a];
+#pragma unroll 1
+                    for (int bb = 0; bb <= a; ++bb) {
+                        double sum = sa * Tc[bb * 32 + wa];
+#pragma unroll 1
+                        for (int c = 0; c < bb; ++c) sum -= Lk[a * L::LDL + c] * Lk[bb * L::LDL + c];
+                        if (a == bb) Lk[a * L::LDL + a] = sqrt(fmax(sum, 1e-300));
+                        else Lk[a * L::LDL + bb] = sum / Lk[bb * L::LDL + bb];
+                    }
+                    double y = sa * tpb[wa];
+#pragma unroll 1
+                    for (int c = 0; c < a; ++c) y -= Lk[a * L::LDL + c] * rvec[c];
+                    rvec[a] = y / Lk[a * L::LDL + a];
+                }
+#pragma unroll 1
+                for (int a = nW - 1; a >= 0; --a) {
+                    double y = rvec[a];
+#pragma unroll 1
+                    for (int c = a + 1; c < nW; ++c) y -= Lk[c * L::LDL + a] * rvec[c];
+                    rvec[a] = y / Lk[a * L::LDL + a];
+                }
+                // primal step z = tp - sum_a r_a Tc[a]
+                double z = tp;
+#pragma unroll 1
+                for (int a = 0; a < nW; ++a) z = fma(-rvec[a], Tc[a * 32 + i], z);
+                zbuf[i] = z;
+                wcqp::wave_lds_fence();
+                const double nz = sig * zbuf[p];
+                const double t2 = nz > 1e-12 * ppp ? s / nz : inf;
+                double t1 = inf;
+                int jd = -1;
+#pragma unroll 1
+                for (int a = 0; a < nW; ++a) {
+                    const double ra = rvec[a];
+                    if (ra > 0.0) {
+                        const double tt = Wmu[a] / ra;
+                        if (tt < t1) { t1 = tt; jd = a; }
+                    }
+                }
+                const double t = fmin(t1, t2);
+                if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; running = false; break; }
+                nu = fma(-t, z, nu);
+#pragma unroll 1
+                for (int a = 0; a < nW; ++a) Wmu[a] = Wmu[a] - t * rvec[a];
+                mu_p += t;
+                s -= t * nz;
+                if (t2 <= t1) {                          // full step: p joins W
+                    Tc[nW * 32 + i] = tp;
+                    Wi[nW] = p; Wsg[nW] = sig; Wmu[nW] = mu_p;
+                    if (i == p) { in_w = true; my_sig = sig; }
+                    ++nW;
+                    break;
+                }
+                // partial step: constraint jd leaves W
+                if (i == Wi[jd]) { in_w = false; my_sig = 0.0; }
+#pragma unroll 1
+                for (int a = jd; a < nW - 1; ++a) {
+                    Tc[a * 32 + i] = Tc[(a + 1) * 32 + i];
+                    const int w1 = Wi[a + 1]; const double s1 = Wsg[a + 1], m1 = Wmu[a + 1];
+                    Wi[a] = w1; Wsg[a] = s1; Wmu[a] = m1;
+                }
+                --nW;
+                ++it;
+                wcqp::wave_lds_fence();
+            }
+            wcqp::wave_lds_fence();
+        }
+    }
+
+    // ---------------- outputs ------------------------------------------------------------
+    const unsigned long long bu = __ballot(in_w && my_sig > 0.0);
+    const unsigned long long bl = __ballot(in_w && my_sig < 0.0);
+    if (live) {
+        if (i >= 6 && var) dq_out[inst * kDof + (i - 6)] = nu;
+        if (i == 0) {
+            status_out[inst] = st_code;
+            if (aup_out) aup_out[inst] = (unsigned)((bu >> (32 * half)) & 0xffffffffull) >> 6;
+            if (alo_out) alo_out[inst] = (unsigned)((bl >> (32 * half)) & 0xffffffffull) >> 6;
+            if (iters_out) iters_out[inst] = it;
+        }
+    }
+    if (ferr_out) {
+        // "foot errors" = b - J nu  (osqp.cpp:430-454, qp.cpp:364-401)
+        double* nub = S + L::OFF_V0;
+        wcqp::wave_lds_fence();
+        nub[i] = var ? nu : 0.0;
+        wcqp::wave_lds_fence();
+        if (i < 12 && live) {
+            const double* jrow = (i < 6 ? JL + inst * (6 * kNV) + i * kNV : JR + inst * (6 * kNV) + (i - 6) * kNV);
+            double acc = b_mine;
+            for (int k = 0; k < kNV; ++k) acc = fma(-jrow[k], nub[k], acc);
+            ferr_out[inst * 12 + i] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+// ======================================================================================
+struct wcqp_ik_s {
+    wcqp_ik_params p{};
+    IkDeviceParams hp{};
+    IkDeviceParams* d_prm = nullptr;
+    wcqp::DeviceScratch scratch;
+};
+
+namespace {
+
+int ensure_device(wcqp_ik_s* h) {
+    if (h->d_prm) return WCQP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        std::fprintf(stderr, "[wcqp] no HIP device: the IK solve path has no CPU fallback\n");
+        return WCQP_E_HIP;
+    }
+    WCQP_HIP_TRY(hipMalloc(&h->d_prm, sizeof(IkDeviceParams)));
+    WCQP_HIP_TRY(hipMemcpy(h->d_prm, &h->hp, sizeof(IkDeviceParams), hipMemcpyHostToDevice));
+    return WCQP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out) {
+    if (!params || !out) return WCQP_E_INVALID;
+    if (params->dof != kDof) return WCQP_E_UNSUPPORTED;      // kernels are unrolled for iCub's 23 DoF
+    if (params->form != WCQP_IK_FORM_QPOASES && params->form != WCQP_IK_FORM_OSQP) return WCQP_E_INVALID;
+    wcqp_ik_s* h = new (std::nothrow) wcqp_ik_s();
+    if (!h) return WCQP_E_NOMEM;
+    h->p = *params;
+    IkDeviceParams& d = h->hp;
+    const double big = std::numeric_limits<double>::max();
+    for (int i = 0; i < 32; ++i) {
+        d.lam[i] = d.kq[i] = d.qreg[i] = 0.0;
+        d.vlo[i] = -big; d.vhi[i] = big;                       // qp.cpp:39-43
+    }
+    for (int j = 0; j < kDof; ++j) {
+        d.lam[6 + j] = params->joint_reg_weights[j];           // base.cpp:64-67
+        d.kq[6 + j] = params->joint_reg_weights[j] * params->joint_reg_gains[j];   // base.cpp:70-72, 87-89
+        d.qreg[6 + j] = params->joint_reg_rad[j];
+        d.vlo[6 + j] = params->v_min[j];                       // qp.cpp:45-49
+        d.vhi[6 + j] = params->v_max[j];
+        if (!(params->v_min[j] <= params->v_max[j])) { delete h; return WCQP_E_INVALID; }
+    }
+    std::memcpy(d.Wn, params->neck_weight, sizeof(d.Wn));
+    std::memcpy(d.Wc, params->com_weight, sizeof(d.Wc));
+    d.k_pos_com = params->k_pos_com; d.k_pos_foot = params->k_pos_foot;
+    d.k_att_foot = params->k_att_foot; d.k_neck = params->k_neck;
+    // extra k_attFoot on the neck gradient term in the osqp back-end only (osqp.cpp:183,193)
+    d.kappa = params->form == WCQP_IK_FORM_OSQP ? params->k_att_foot : 1.0;
+    d.rho = params->rho > 0 ? params->rho : 1.0;
+    d.tol = params->tol > 0 ? params->tol : 1e-12;
+    d.form = params->form;
+    d.max_iter = params->max_iter > 0 ? params->max_iter : 100;   // nWSR = 100, qp.cpp:312
+    *out = h;
+    return WCQP_OK;
+}
+
+int wcqp_ik_destroy(wcqp_ik_t h) {
+    if (!h) return WCQP_E_INVALID;
+    if (h->d_prm) (void)hipFree(h->d_prm);
+    h->scratch.release();
+    delete h;
+    return WCQP_OK;
+}
+
+int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
+                         const double* J_left, const double* J_right, const double* J_neck, const double* J_com,
+                         const double* q, const double* state,
+                         double* dq, int32_t* status, uint32_t* active_lower, uint32_t* active_upper,
+                         double* foot_err, int32_t* iters, void* stream) {
+    if (!h || batch < 0) return WCQP_E_INVALID;
+    if (!J_left || !J_right || !J_neck || !J_com || !q || !state || !dq || !status) return WCQP_E_INVALID;
+    if (batch == 0) return WCQP_OK;
+    const int rc = ensure_device(h);
+    if (rc != WCQP_OK) return rc;
+    const unsigned grid = (unsigned)((batch + 1) / 2);
+    if (h->p.use_com_as_constraint)
+        hipLaunchKernelGGL(ik_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                           h->d_prm, batch, J_left, J_right, J_neck, J_com, q, state,
+                           dq, status, active_lower, active_upper, foot_err, iters);
+    else
+        hipLaunchKernelGGL(ik_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                           h->d_prm, batch, J_left, J_right, J_neck, J_com, q, state,
+                           dq, status, active_lower, active_upper, foot_err, iters);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
+                       const double* J_left, const double* J_right, const double* J_neck, const double* J_com,
+                       const double* q, const double* state,
+                       double* dq, int32_t* status, uint32_t* active_lower, uint32_t* active_upper,
+                       double* foot_err, int32_t* iters) {
+    if (!h || batch < 0) return WCQP_E_INVALID;
+    if (!J_left || !J_right || !J_neck || !J_com || !q || !state || !dq || !status) return WCQP_E_INVALID;
+    if (batch == 0) return WCQP_OK;
+    int rc = ensure_device(h);
+    if (rc != WCQP_OK) return rc;
+    const size_t B = (size_t)batch;
+    const size_t o_jl = 0, o_jr = o_jl + B * 6 * kNV, o_jn = o_jr + B * 6 * kNV, o_jc = o_jn + B * 3 * kNV,
+                 o_q = o_jc + B * 3 * kNV, o_st = o_q + B * kDof, o_dq = o_st + B * kStateLen,
+                 o_fe = o_dq + B * kDof, n_dbl = o_fe + B * 12;
+    rc = h->scratch.reserve(n_dbl * 8 + B * 4 * 4);
+    if (rc != WCQP_OK) return rc;
+    double* d = static_cast<double*>(h->scratch.ptr);
+    int32_t* d_st = reinterpret_cast<int32_t*>(d + n_dbl);
+    uint32_t* d_lo = reinterpret_cast<uint32_t*>(d_st + B);
+    uint32_t* d_up = d_lo + B;
+    int32_t* d_it = reinterpret_cast<int32_t*>(d_up + B);
+    WCQP_HIP_TRY(hipMemcpy(d + o_jl, J_left, B * 6 * kNV * 8, hipMemcpyHostToDevice));
+    WCQP_HIP_TRY(hipMemcpy(d + o_jr, J_right, B * 6 * kNV * 8, hipMemcpyHostToDevice));
+    WCQP_HIP_TRY(hipMemcpy(d + o_jn, J_neck, B * 3 * kNV * 8, hipMemcpyHostToDevice));
+    WCQP_HIP_TRY(hipMemcpy(d + o_jc, J_com, B * 3 * kNV * 8, hipMemcpyHostToDevice));
+    WCQP_HIP_TRY(hipMemcpy(d + o_q, q, B * kDof * 8, hipMemcpyHostToDevice));
+    WCQP_HIP_TRY(hipMemcpy(d + o_st, state, B * kStateLen * 8, hipMemcpyHostToDevice));
+    rc = wcqp_ik_solve_device(h, batch, d + o_jl, d + o_jr, d + o_jn, d + o_jc, d + o_q, d + o_st,
+                              d + o_dq, d_st, d_lo, d_up, foot_err ? d + o_fe : nullptr, d_it, nullptr);
+    if (rc != WCQP_OK) return rc;
+    WCQP_HIP_TRY(hipDeviceSynchronize());
+    WCQP_HIP_TRY(hipMemcpy(dq, d + o_dq, B * kDof * 8, hipMemcpyDeviceToHost));
+    WCQP_HIP_TRY(hipMemcpy(status, d_st, B * 4, hipMemcpyDeviceToHost));
+    if (active_lower) WCQP_HIP_TRY(hipMemcpy(active_lower, d_lo, B * 4, hipMemcpyDeviceToHost));
+    if (active_upper) WCQP_HIP_TRY(hipMemcpy(active_upper, d_up, B * 4, hipMemcpyDeviceToHost));
+    if (foot_err) WCQP_HIP_TRY(hipMemcpy(foot_err, d + o_fe, B * 12 * 8, hipMemcpyDeviceToHost));
+    if (iters) WCQP_HIP_TRY(hipMemcpy(iters, d_it, B * 4, hipMemcpyDeviceToHost));
+    return WCQP_OK;
+}
+
+}  // extern "C"

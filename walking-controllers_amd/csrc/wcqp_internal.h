@@ -1,0 +1,54 @@
+// Internal helpers shared by the translation units of libwcqp (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+#include "wcqp.h"
+
+#define WCQP_HIP_TRY(expr)                                                         \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            std::fprintf(stderr, "[wcqp] %s failed: %s (%s:%d)\n", #expr,          \
+                         hipGetErrorString(e__), __FILE__, __LINE__);              \
+            return WCQP_E_HIP;                                                     \
+        }                                                                          \
+    } while (0)
+
+namespace wcqp {
+
+// Dense LU with partial pivoting, row-major, in place; returns false when singular.
+bool lu_factor(std::vector<double>& a, int n, std::vector<int>& piv);
+void lu_solve(const std::vector<double>& lu, const std::vector<int>& piv, int n, double* b);
+
+// A growable device scratch buffer owned by a handle (used only by *_host entry points).
+struct DeviceScratch {
+    void*  ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+};
+
+// ---- wave-level helpers used by the kernels (gfx950, wave64) -------------------------
+#if defined(__HIPCC__)
+// Orders LDS traffic between lanes of ONE wavefront: the LDS pipeline executes a
+// wave's DS instructions in program order, so only the compiler has to be told
+// not to move them across this point.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 1/x: v_rcp_f64 seed + two Newton steps (error <= ~1 ulp; the QPs need 1e-9, not
+// correctly-rounded division, and the IEEE division sequence is ~3x longer).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+#endif
+
+}  // namespace wcqp

@@ -1,0 +1,260 @@
+"""
+Synthetic iCub-shaped workloads in the batch
+layouts of the C ABI (`include/wcqp.h`).
+
+Every number depends only on (seed, global instance index, slot), through a
+counter-based 64-bit mixer, so any shard [first, first+count) of a batch is
+bit-identical to the same rows of the full batch whatever the shard count —
+this is what lets the multi-GPU path be checked for shard-count invariance.
+
+The constants are the values shipped in the reference's
+app/robots/iCubGazeboV2_5/{controllerParams,qpInverseKinematics,plannerParams}.ini
+(values only; no parser is reproduced here).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+HULL_ROWS = 8            # hull rows are padded to 8 per instance (n_c in 4..8)
+HULL_PAD_B = 1e30        # padded rows: 0*u <= +OsqpEigen::INFTY
+IK_STATE_LEN = 87        # packed pose block, see IK_STATE_OFFSETS
+
+# offsets inside the packed per-instance IK state block (doubles)
+IK_STATE_OFFSETS = dict(
+    p_left=0, R_left=3, p_right=12, R_right=15,
+    pd_left=24, Rd_left=27, pd_right=36, Rd_right=39,
+    R_neck=48, Rd_neck=57,
+    com=66, com_des=69, com_vel_des=72,
+    twist_left=75, twist_right=81,
+)
+
+FOOT_X = (-0.02, 0.05)       # controllerParams.ini:7  foot_size
+FOOT_Y = (-0.025, 0.025)
+NOMINAL_WIDTH = 0.16         # plannerParams.ini:27
+
+ICUB_JOINT_REG_DEG = np.array([15, 0, 0,
+                               -7, 22, 11, 30,
+                               -7, 22, 11, 30,
+                               5.082, 0.406, -0.131, -45.249, -26.454, -0.351,
+                               5.082, 0.406, -0.131, -45.249, -26.454, -0.351], float)
+
+_M1 = np.uint64(0x9E3779B97F4A7C15)
+_M2 = np.uint64(0xBF58476D1CE4E5B9)
+_M3 = np.uint64(0x94D049BB133111EB)
+
+
+def _mix(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64, copy=True)
+    x ^= x >> np.uint64(30)
+    x *= _M2
+    x ^= x >> np.uint64(27)
+    x *= _M3
+    x ^= x >> np.uint64(31)
+    return x
+
+
+class CounterRNG:
+    """Stateless counter-based generator: value(seed, instance, slot)."""
+
+    def __init__(self, seed: int, first: int, count: int):
+        self.seed = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+        self.inst = np.arange(first, first + count, dtype=np.uint64)
+        self._slot = 0
+
+    def _bits(self, k: int) -> np.ndarray:
+        slots = np.arange(self._slot, self._slot + k, dtype=np.uint64)
+        self._slot += k
+        with np.errstate(over="ignore"):
+            base = _mix(self.inst * _M1 + self.seed)[:, None]
+            return _mix(base + (slots[None, :] + np.uint64(1)) * _M3)
+
+    def uniform(self, k: int, lo: float = 0.0, hi: float = 1.0) -> np.ndarray:
+        u = (self._bits(k) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        return lo + (hi - lo) * u
+
+    def normal(self, k: int, sigma: float = 1.0) -> np.ndarray:
+        k2 = (k + 1) // 2
+        u1 = 1.0 - self.uniform(k2)          # (0, 1]
+        u2 = self.uniform(k2)
+        r = np.sqrt(-2.0 * np.log(u1))
+        z = np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)], axis=1)
+        return sigma * z[:, :k]
+
+
+# --------------------------------------------------------------------------------------
+# support polygon -> hull rows  (our own convention, SURVEY Appendix D-4:
+# CCW hull, unit outward normals, rows a.u <= b, padded to 8 with 0.u <= 1e30)
+# --------------------------------------------------------------------------------------
+def convex_hull_ccw(pts: np.ndarray) -> np.ndarray:
+    """Andrew monotone chain; returns CCW vertices without collinear points."""
+    P = sorted(map(tuple, np.asarray(pts, float)))
+    if len(P) <= 2:
+        return np.array(P)
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    lo, up = [], []
+    for p in P:
+        while len(lo) >= 2 and cross(lo[-2], lo[-1], p) <= 0:
+            lo.pop()
+        lo.append(p)
+    for p in reversed(P):
+        while len(up) >= 2 and cross(up[-2], up[-1], p) <= 0:
+            up.pop()
+        up.append(p)
+    return np.array(lo[:-1] + up[:-1])
+
+
+def hull_rows(pts: np.ndarray):
+    """rows (A[8,2], b[8], nc) of the convex hull of 2-D points."""
+    V = convex_hull_ccw(pts)
+    nc = len(V)
+    assert 3 <= nc <= HULL_ROWS, nc
+    A = np.zeros((HULL_ROWS, 2))
+    b = np.full(HULL_ROWS, HULL_PAD_B)
+    for k in range(nc):
+        v0, v1 = V[k], V[(k + 1) % nc]
+        d = v1 - v0
+        nrm = np.array([d[1], -d[0]]) / np.hypot(d[0], d[1])
+        A[k] = nrm
+        b[k] = nrm @ v0
+    return A, b, nc
+
+
+def foot_corners(pos_xy: np.ndarray, yaw: float) -> np.ndarray:
+    c, s = np.cos(yaw), np.sin(yaw)
+    R = np.array([[c, -s], [s, c]])
+    loc = np.array([[FOOT_X[1], FOOT_Y[1]], [FOOT_X[1], FOOT_Y[0]],
+                    [FOOT_X[0], FOOT_Y[0]], [FOOT_X[0], FOOT_Y[1]]])
+    return loc @ R.T + pos_xy
+
+
+def synth_mpc_batch(count: int, seed: int = 1234, horizon: int = 50, first: int = 0,
+                    dT: float = 0.01, x0_sigma: float = 0.01, uprev_sigma: float = 0.005):
+    """SURVEY.md §8d config 2.  Returns dict of C-contiguous arrays."""
+    N = horizon
+    rng = CounterRNG(seed, first, count)
+    u_state = rng.uniform(1)[:, 0]
+    yaw = rng.uniform(2, -0.3, 0.3)
+    other_x = rng.uniform(1, -0.1, 0.1)[:, 0]
+    other_y = rng.uniform(1, -0.02, 0.02)[:, 0]
+    x0_n = rng.normal(2, x0_sigma)
+    v = rng.uniform(2, -0.2, 0.2)
+    up_n = rng.normal(2, uprev_sigma)
+    ref_n = rng.normal(2 * (N + 1), 1e-4).reshape(count, N + 1, 2)
+
+    hull_A = np.zeros((count, HULL_ROWS, 2))
+    hull_b = np.zeros((count, HULL_ROWS))
+    hull_nc = np.zeros(count, np.int32)
+    centroid = np.zeros((count, 2))
+    contact = np.zeros(count, np.int32)       # 0 = left only, 1 = right only, 2 = both
+    for i in range(count):
+        st = 0 if u_state[i] < 0.35 else (1 if u_state[i] < 0.70 else 2)
+        contact[i] = st
+        # stance foot at the origin; the other foot nominal-width away (left is +y)
+        if st == 0:
+            pts = foot_corners(np.zeros(2), yaw[i, 0])
+        elif st == 1:
+            pts = foot_corners(np.zeros(2), yaw[i, 1])
+        else:
+            left = foot_corners(np.zeros(2), yaw[i, 0])
+            right = foot_corners(np.array([other_x[i], -NOMINAL_WIDTH + other_y[i]]), yaw[i, 1])
+            pts = np.vstack([left, right])
+        A, b, nc = hull_rows(pts)
+        hull_A[i], hull_b[i], hull_nc[i] = A, b, nc
+        centroid[i] = convex_hull_ccw(pts).mean(axis=0)
+    x0 = centroid + x0_n
+    stage = np.arange(N + 1, dtype=float)[None, :, None]
+    ref = x0[:, None, :] + stage * v[:, None, :] * dT + ref_n
+    u_prev = centroid + up_n
+    return dict(x0=np.ascontiguousarray(x0), ref=np.ascontiguousarray(ref),
+                u_prev=np.ascontiguousarray(u_prev), hull_A=hull_A, hull_b=hull_b,
+                hull_nc=hull_nc, contact=contact, centroid=centroid)
+
+
+# --------------------------------------------------------------------------------------
+def _skew(p: np.ndarray) -> np.ndarray:
+    z = np.zeros(p.shape[0])
+    return np.stack([np.stack([z, -p[:, 2], p[:, 1]], -1),
+                     np.stack([p[:, 2], z, -p[:, 0]], -1),
+                     np.stack([-p[:, 1], p[:, 0], z], -1)], -2)
+
+
+def _small_rot(w: np.ndarray) -> np.ndarray:
+    """Rodrigues for a batch of rotation vectors (count, 3)."""
+    th = np.linalg.norm(w, axis=1)
+    th_safe = np.where(th > 0, th, 1.0)
+    K = _skew(w / th_safe[:, None])
+    I = np.eye(3)[None]
+    s = np.sin(th)[:, None, None]
+    c = (1 - np.cos(th))[:, None, None]
+    return I + s * K + c * (K @ K)
+
+
+def _rotz(a: np.ndarray) -> np.ndarray:
+    c, s, z, o = np.cos(a), np.sin(a), np.zeros_like(a), np.ones_like(a)
+    return np.stack([np.stack([c, -s, z], -1), np.stack([s, c, z], -1), np.stack([z, z, o], -1)], -2)
+
+
+def synth_ik_batch(count: int, seed: int = 4321, dof: int = 23, first: int = 0,
+                   joint_sigma: float = 0.3, com_sigma: float = 0.05):
+    """SURVEY.md §8d config 3 (dense random joint columns, exact mixed-representation
+    base blocks).  Returns dict of C-contiguous arrays in ABI layout."""
+    n = dof + 6
+    rng = CounterRNG(seed, first, count)
+    o = IK_STATE_OFFSETS
+
+    def jac6():
+        p = rng.normal(3, 0.3)
+        J = np.zeros((count, 6, n))
+        J[:, 0:3, 0:3] = np.eye(3)
+        J[:, 0:3, 3:6] = -_skew(p)
+        J[:, 3:6, 3:6] = np.eye(3)
+        J[:, :, 6:] = rng.normal(6 * dof, joint_sigma).reshape(count, 6, dof)
+        return J
+
+    J_left, J_right, J_neck6 = jac6(), jac6(), jac6()
+    pc = rng.normal(3, 0.3)
+    J_com = np.zeros((count, 3, n))
+    J_com[:, :, 0:3] = np.eye(3)
+    J_com[:, :, 3:6] = -_skew(pc)
+    J_com[:, :, 6:] = rng.normal(3 * dof, com_sigma).reshape(count, 3, dof)
+
+    q_reg = np.deg2rad(ICUB_JOINT_REG_DEG if dof == 23 else np.zeros(dof))
+    q = q_reg[None, :] + rng.normal(dof, 0.05)
+
+    state = np.zeros((count, IK_STATE_LEN))
+    yaw = rng.uniform(3, -0.3, 0.3)
+    # desired feet: left at origin-ish, right nominal-width away; small yaw
+    pd_left = np.concatenate([rng.uniform(2, -0.1, 0.1), np.zeros((count, 1))], 1)
+    pd_right = pd_left + np.array([0.0, -NOMINAL_WIDTH, 0.0]) + \
+        np.concatenate([rng.uniform(2, -0.05, 0.05), rng.uniform(1, 0.0, 0.03)], 1)
+    Rd_left, Rd_right = _rotz(yaw[:, 0]), _rotz(yaw[:, 1])
+    R_left = _small_rot(rng.normal(3, 0.01)) @ Rd_left
+    R_right = _small_rot(rng.normal(3, 0.01)) @ Rd_right
+    p_left = pd_left + rng.normal(3, 0.005)
+    p_right = pd_right + rng.normal(3, 0.005)
+    Rd_neck = _rotz(yaw[:, 2]) @ np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    R_neck = _small_rot(rng.normal(3, 0.02)) @ Rd_neck
+    com_des = 0.5 * (pd_left + pd_right) + np.array([0.0, 0.0, 0.53])
+    com = com_des + rng.normal(3, 0.005)
+    com_vel = rng.normal(3, 0.05)
+    stance_left = rng.uniform(1)[:, 0] < 0.5
+    tw = rng.normal(6, 0.2)
+    twist_left = np.where(stance_left[:, None], 0.0, tw)
+    twist_right = np.where(stance_left[:, None], tw, 0.0)
+
+    def put(name, arr):
+        a = arr.reshape(count, -1)
+        state[:, o[name]:o[name] + a.shape[1]] = a
+
+    put("p_left", p_left); put("R_left", R_left); put("p_right", p_right); put("R_right", R_right)
+    put("pd_left", pd_left); put("Rd_left", Rd_left); put("pd_right", pd_right); put("Rd_right", Rd_right)
+    put("R_neck", R_neck); put("Rd_neck", Rd_neck)
+    put("com", com); put("com_des", com_des); put("com_vel_des", com_vel)
+    put("twist_left", twist_left); put("twist_right", twist_right)
+
+    return dict(J_left=np.ascontiguousarray(J_left), J_right=np.ascontiguousarray(J_right),
+                J_neck=np.ascontiguousarray(J_neck6[:, 3:6, :]), J_com=np.ascontiguousarray(J_com),
+                q=np.ascontiguousarray(q), state=state)
