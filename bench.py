@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""
+bench.py — whole-job QP solves/s of the MI355X batched solve path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic robot instances:
+one DCM-MPC QP (N = 50, BASELINE configs[1]) and one Jacobian QP-IK (iCub 23 DoF,
+BASELINE configs[2]) per instance, i.e. 2 QP solves per robot-tick, `--batch`
+instances per GPU (default 4096, the batch both configs are quoted on), every
+instance cold-started.  Inputs are resident in HBM before the timed region starts.
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Instances are independent, so ranks shard the batch with no data-path collective
+(`scaling: weak`, fixed per-GPU batch); `--exchange` adds the RCCL scatter of inputs from
+rank 0 and gather of solutions to every step and reports that rate too.
+
+The JSON line carries
+  roofline      HBM roofline of the dominant kernel (the IK kernel): algorithmic bytes per
+                launch (5240 B/IK-QP x batch) / its average launch duration,
+                measured with HIP events on the launch stream over the timed steps;
+  cpu_baseline  oracle/wc_oracle.c (OSQP-algorithm restatement for the MPC, dense dual
+                active set for the IK) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "QP solves/sec (whole node), iCub IK-QP + DCM-MPC batch at 1/2/4/8 MI355X"
+IK_BYTES_PER_QP = 5240      # 632 doubles in + 23 doubles out
+MPC_BYTES_PER_QP = 1056     # 130 doubles in + 2 doubles out
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="robot instances per GPU")
+    ap.add_argument("--ik-vmax", type=float, default=0.5, help="joint velocity limit of the synthetic robots [rad/s]")
+    ap.add_argument("--ik-form", choices=["qpoases", "osqp"], default="qpoases")
+    ap.add_argument("--exchange", action="store_true", help="RCCL scatter inputs / gather solutions every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import walking_controllers_amd as wca
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the solve path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    B = args.batch
+    first = rank * B
+    # ---- synthetic inputs (each rank generates its own shard: identical to the rows a rank-0
+    # scatter would hand it, walking-controllers_amd/synth.py is counter-based) -------------
+    mb = wca.synth.synth_mpc_batch(B, seed=1234, first=first)
+    ib = wca.synth.synth_ik_batch(B, seed=4321, first=first)
+
+    def up(a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(dev) if dtype is None else t.to(dev, dtype)
+
+    d = {k: up(mb[k]) for k in ("x0", "ref", "u_prev", "hull_A", "hull_b")}
+    d["hull_nc"] = up(mb["hull_nc"])
+    d.update({k: up(ib[k]) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")})
+    u0 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+    mstat = torch.zeros(B, dtype=torch.int32, device=dev)
+    mact = torch.zeros(B, dtype=torch.int32, device=dev)
+    mmar = torch.zeros(B, dtype=torch.float64, device=dev)
+    dq = torch.zeros(B, 23, dtype=torch.float64, device=dev)
+    istat = torch.zeros(B, dtype=torch.int32, device=dev)
+    ilo = torch.zeros(B, dtype=torch.int32, device=dev)
+    iup = torch.zeros(B, dtype=torch.int32, device=dev)
+    iit = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    mpc = wca.MpcSolver(horizon=50)
+    ik = wca.IkSolver(form=wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP, v_max=args.ik_vmax)
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream
+    N1 = mb["ref"].shape[1]
+
+    def launch_mpc():
+        mpc.solve_device(B, d["x0"].data_ptr(), d["ref"].data_ptr(), N1, d["u_prev"].data_ptr(),
+                         d["hull_A"].data_ptr(), d["hull_b"].data_ptr(), d["hull_nc"].data_ptr(),
+                         u0.data_ptr(), mstat.data_ptr(), mact.data_ptr(), mmar.data_ptr(), sp)
+
+    def launch_ik():
+        ik.solve_device(B, d["J_left"].data_ptr(), d["J_right"].data_ptr(), d["J_neck"].data_ptr(),
+                        d["J_com"].data_ptr(), d["q"].data_ptr(), d["state"].data_ptr(),
+                        dq.data_ptr(), istat.data_ptr(), ilo.data_ptr(), iup.data_ptr(), 0, iit.data_ptr(), sp)
+
+    # optional RCCL exchange (rank 0 owns the whole batch)
+    exch = None
+    if args.exchange and world > 1:
+        in_keys = ("x0", "ref", "u_prev", "hull_A", "hull_b", "J_left", "J_right", "J_neck", "J_com", "q", "state")
+        if rank == 0:
+            full = {k: [torch.empty_like(d[k]) for _ in range(world)] for k in in_keys}
+            for k in in_keys:
+                for r in range(world):
+                    full[k][r].copy_(d[k])           # shape-true stand-ins: only the traffic matters here
+            gat_u0 = [torch.empty_like(u0) for _ in range(world)]
+            gat_dq = [torch.empty_like(dq) for _ in range(world)]
+        else:
+            full, gat_u0, gat_dq = None, None, None
+
+        def exch_in():
+            for k in in_keys:
+                dist.scatter(d[k], full[k] if rank == 0 else None, src=0)
+
+        def exch_out():
+            dist.gather(u0, gat_u0 if rank == 0 else None, dst=0)
+            dist.gather(dq, gat_dq if rank == 0 else None, dst=0)
+        exch = (exch_in, exch_out)
+
+    def step(ev=None):
+        if exch:
+            exch[0]()
+        launch_mpc()
+        if ev is not None:
+            ev[0].record(stream)
+        launch_ik()
+        if ev is not None:
+            ev[1].record(stream)
+        if exch:
+            exch[1]()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    mpc_ev = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ik_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))      # IK kernel, HIP events on its stream
+    # MPC kernel duration: a short separately timed run (it is not the dominant kernel)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(50):
+        launch_mpc()
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    mpc_ms = e0.elapsed_time(e1) / 50.0
+
+    # sanity: the timed work really solved the problems
+    n_ok_ik = int((istat == 0).sum().item())
+    n_ok_mpc = int((mstat == 0).sum().item())
+    ik_iters = float(iit.double().mean().item())
+    frac_active = float(((ilo | iup) != 0).double().mean().item())
+
+    total_qp = 2 * B * world * args.steps
+    value = total_qp / elapsed
+    out = {
+        "metric": METRIC, "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE configs[1]+[2] per GPU: DCM-MPC QP (N=50, n=202, cold start) B=%d + QP-IK "
+                         "(iCub 23 DoF, 15 eq rows, %s form, v_max=%.2f rad/s) B=%d; 2 QP solves per robot-tick"
+                         % (B, args.ik_form, args.ik_vmax, B)),
+            "batch_per_gpu": B, "global_batch": B * world, "horizon": 50, "dof": 23,
+            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s" % (world, " + RCCL scatter/gather" if exch else ""),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "ik_kernel<true>",
+            "achieved": IK_BYTES_PER_QP * B / (ik_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": IK_BYTES_PER_QP * B / (ik_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "avg_launch_ms": ik_ms, "algorithmic_bytes_per_launch": IK_BYTES_PER_QP * B,
+        },
+        "kernels": {
+            "ik_ms": ik_ms, "ik_qps_per_gpu": B / (ik_ms * 1e-3),
+            "mpc_ms": mpc_ms, "mpc_qps_per_gpu": B / (mpc_ms * 1e-3),
+            "mpc_hbm_frac": MPC_BYTES_PER_QP * B / (mpc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        },
+        "solved": {"ik": n_ok_ik, "mpc": n_ok_mpc, "of": B, "ik_mean_active_set_changes": ik_iters,
+                   "ik_frac_with_active_bounds": frac_active},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            if int(tr.get("batch", -1)) == B:
+                out["roofline"]["traffic"] = tr.get("ik_hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(mb, ib, args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(mb, ib, args):
+    """oracle/wc_oracle.c on the host cores: the reference's CPU algorithms (OSQP for the MPC,
+    an active-set method for the qpOASES-form IK) restated in C — `kind: port`."""
+    from oracle import c_oracle as co
+    from oracle import qp_spec as qs
+    cores = min(co.num_threads(), os.cpu_count() or 1)
+    mp = qs.MPCParams()
+    ipar = qs.IKParams(v_max=args.ik_vmax * np.ones(23))
+    # calibrate on a small slice, then size the sample to ~cpu_seconds of CPU work
+    def take(b, n):
+        return {k: v[:n] for k, v in b.items()}
+    t = time.perf_counter(); co.mpc_batch_osqp(mp, take(mb, 64), nthreads=cores); t_m = (time.perf_counter() - t) / 64 * cores
+    t = time.perf_counter(); co.ik_batch(ipar, take(ib, 64), args.ik_form, nthreads=cores); t_i = (time.perf_counter() - t) / 64 * cores
+    n = int(max(256, min(len(mb["x0"]), args.cpu_seconds / max(t_m + t_i, 1e-9))))
+    n = min(n, len(mb["x0"]))
+    reps = max(1, int(round(args.cpu_seconds / max((t_m + t_i) * n, 1e-9))))
+    t = time.perf_counter()
+    for _ in range(reps):
+        co.mpc_batch_osqp(mp, take(mb, n), nthreads=cores)
+    wall_m = time.perf_counter() - t
+    t = time.perf_counter()
+    for _ in range(reps):
+        co.ik_batch(ipar, take(ib, n), args.ik_form, nthreads=cores)
+    wall_i = time.perf_counter() - t
+    return {"value": 2 * n * reps / (wall_m + wall_i), "unit": "QP/s", "cores": cores, "kind": "port",
+            "sample": "%d x the first %d instances of the same workload (1 MPC via OSQP-restatement + 1 IK via %s per instance), "
+                      "OpenMP static split" % (reps, n, "dense active set" if args.ik_form == "qpoases" else "OSQP-restatement"),
+            "mpc_qps": n * reps / wall_m, "ik_qps": n * reps / wall_i}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""
+CPU tests of the C ABI library and the host logic around it: the library loads, exports
+every symbol include/wcqp.h declares, builds the reference's constant blocks, condenses
+them correctly, validates arguments — and REFUSES to solve without a GPU (no CPU fallback).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(wca):
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "wcqp.h")).read()
+    declared = set(re.findall(r"\b(wcqp_[a-z_]+)\s*\(", hdr))
+    assert declared == set(wca.capi.ABI_SYMBOLS)
+    lib = wca.capi.lib()
+    for s in declared:
+        assert getattr(lib, s) is not None
+    assert lib.wcqp_version() == 100
+    assert lib.wcqp_strerror(-4).decode().startswith("HIP")
+
+
+def test_mpc_constants_match_reference_blocks(wca, qs):
+    """wcqp_mpc_create restates initializeMatrices; compare with the oracle's blocks exactly."""
+    for N in (2, 7, 50):
+        m = wca.MpcSolver(horizon=N)
+        P, A, G = m.matrices()
+        c = qs.mpc_constants(qs.MPCParams(horizon=N))
+        assert np.array_equal(P, c.P) and np.array_equal(A, c.A_eq) and np.array_equal(G, c.grad_sub)
+
+
+def test_mpc_condensing_is_the_kkt_inverse(wca, qs):
+    """u0_unc = sum Gr_i r_i + Gx x0 + Gu u_prev must equal the equality-only KKT solve, and
+    Sigma0 the u0 block of K^-1 — for isotropic and for coupled (non-diagonal) weights."""
+    rng = np.random.default_rng(3)
+    for Q, R in ((7500.0 * np.eye(2), 9e6 * np.eye(2)),
+                 (np.array([[7.0, 2.0], [2.0, 5.0]]), np.array([[90.0, -10.0], [-10.0, 40.0]]))):
+        N = 12
+        m = wca.MpcSolver(horizon=N, Q=Q, R=R)
+        Gr, Gx, Gu, S0 = m.condensed()
+        c = qs.mpc_constants(qs.MPCParams(horizon=N, Q=Q, R=R))
+        x0, up, ref = rng.normal(size=2), rng.normal(size=2), rng.normal(size=(N + 1, 2))
+        P, q, A, l, u = qs.mpc_assemble(c, x0, ref, up, np.zeros((0, 2)), np.zeros(0))
+        z, lam = qs._kkt_solve(P, q, A, u)
+        u0 = np.einsum("iab,ib->a", Gr, ref) + Gx @ x0 + Gu @ up
+        assert np.abs(u0 - z[c.n_x:c.n_x + 2]).max() < 1e-9 * max(1.0, np.abs(z).max())
+        K = np.block([[P, A.T], [A, np.zeros((c.n_x, c.n_x))]])
+        assert np.allclose(S0, np.linalg.inv(K)[c.n_x:c.n_x + 2, c.n_x:c.n_x + 2], rtol=1e-8, atol=0)
+
+
+def test_argument_validation(wca):
+    lib = wca.capi.lib()
+    h = C.c_void_p()
+    assert lib.wcqp_mpc_create(None, C.byref(h)) == -1
+    with pytest.raises(wca.WcqpError):
+        wca.MpcSolver(horizon=0)
+    with pytest.raises(wca.WcqpError):
+        wca.MpcSolver(Q=np.array([[1.0, 2.0], [3.0, 1.0]]))      # non-symmetric weight
+    with pytest.raises(wca.WcqpError):
+        wca.IkSolver(dof=12, joint_reg_weights=np.ones(12), joint_reg_gains=np.ones(12),
+                     joint_reg_rad=np.zeros(12), v_max=np.ones(12))   # kernels are built for 23 DoF
+    with pytest.raises(wca.WcqpError):
+        wca.IkSolver(v_min=np.ones(23), v_max=-np.ones(23))
+
+
+def test_no_cpu_fallback(wca):
+    """On a host without a GPU the solve entry points fail loudly; nothing routes to the oracle."""
+    if wca.device_count() > 0:
+        pytest.skip("GPU present")
+    b = wca.synth.synth_mpc_batch(4)
+    with pytest.raises(wca.WcqpError, match="HIP"):
+        wca.MpcSolver().solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    ib = wca.synth.synth_ik_batch(2)
+    with pytest.raises(wca.WcqpError, match="HIP"):
+        wca.IkSolver().solve_host(ib["J_left"], ib["J_right"], ib["J_neck"], ib["J_com"], ib["q"], ib["state"])
+    src = open(os.path.join(os.path.dirname(wca.capi.__file__), "capi.py")).read()
+    assert "oracle" not in src.replace("no fallback", "")
+
+
+def test_synthetic_batches_are_shard_invariant(wca):
+    full_m = wca.synth.synth_mpc_batch(64, seed=5)
+    full_i = wca.synth.synth_ik_batch(64, seed=6)
+    for first, count in ((0, 16), (16, 32), (48, 16)):
+        sm = wca.synth.synth_mpc_batch(count, seed=5, first=first)
+        si = wca.synth.synth_ik_batch(count, seed=6, first=first)
+        for k in ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc"):
+            assert np.array_equal(sm[k], full_m[k][first:first + count])
+        for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state"):
+            assert np.array_equal(si[k], full_i[k][first:first + count])
+
+
+def test_hull_rows_convention(wca):
+    """CCW hull, unit outward normals, a.u <= b, padded to 8 rows with 0.u <= 1e30 (D-4)."""
+    pts = wca.synth.foot_corners(np.zeros(2), 0.0)
+    A, b, nc = wca.synth.hull_rows(pts)
+    assert nc == 4 and np.allclose(np.linalg.norm(A[:4], axis=1), 1.0)
+    assert sorted(np.round(b[:4], 12)) == [0.02, 0.025, 0.025, 0.05]
+    assert not A[4:].any() and (b[4:] == 1e30).all()
+    assert (A[:4] @ np.array([0.01, 0.0]) <= b[:4]).all()
+    two = np.vstack([pts, wca.synth.foot_corners(np.array([0.05, -0.16]), 0.2)])
+    A2, b2, nc2 = wca.synth.hull_rows(two)
+    assert 5 <= nc2 <= 8 and ((A2[:nc2] @ two.T) <= b2[:nc2, None] + 1e-12).all()

@@ -1,0 +1,183 @@
+"""
+CPU tests (-m "not gpu"): the oracle against hand-computable cases, the committed golden
+vectors, and its own C restatement.  The reference has no tests or fixtures for this path
+("parity unpinned"), so the anchors are the formulas of SURVEY Appendix A
+checked on tiny cases and the KKT certificate of the exact optimum.
+"""
+import os
+
+import numpy as np
+import pytest
+
+
+def test_mpc_blocks_tiny_case(qs):
+    """N = 2, isotropic weights: P, A_eq, gradient sub-matrix entry by entry
+    (WalkingDCMModelPredictiveController.cpp:23-168)."""
+    p = qs.MPCParams(horizon=2, Q=3.0 * np.eye(2), R=5.0 * np.eye(2))
+    c = qs.mpc_constants(p)
+    assert (c.n, c.n_x, c.n_u) == (10, 6, 4)
+    th = qs.mpc_theta(2)
+    assert np.array_equal(th, np.array([[1, 0, 0, 0], [0, 1, 0, 0], [-1, 0, 1, 0], [0, -1, 0, 1.0]]))
+    # input cost = |u0 - u_-1|^2_R + |u1 - u0|^2_R  ->  diag 2r, last block r, off-diagonal -r
+    Pu = c.P[6:, 6:]
+    assert np.array_equal(Pu, 5.0 * np.array([[2, 0, -1, 0], [0, 2, 0, -1], [-1, 0, 1, 0], [0, -1, 0, 1.0]]))
+    assert np.array_equal(c.P[:6, :6], 3.0 * np.eye(6)) and not c.P[:6, 6:].any()
+    assert np.array_equal(c.grad_sub, -5.0 * np.array([[1, 0], [0, 1], [0, 0], [0, 0.0]]))
+    a = np.exp(np.sqrt(9.81 / 0.53) * 0.01)
+    assert c.a == pytest.approx(a, rel=1e-15) and c.b == pytest.approx(1 - a, rel=1e-15)
+    # rows 2..3: -x1 + a x0 + b u0 = 0
+    row = c.A_eq[2]
+    assert row[0] == c.a and row[2] == -1.0 and row[6] == c.b and np.count_nonzero(row) == 3
+    assert np.count_nonzero(c.A_eq) == 6 * 2 + 2          # nnz = 6N + 2
+
+
+def test_mpc_sizes_at_baseline_horizon(qs):
+    c = qs.mpc_constants(qs.MPCParams())
+    assert (c.n, c.n_x) == (202, 102)
+    assert np.count_nonzero(c.P) == 398 and np.count_nonzero(c.A_eq) == 302
+    assert c.a == pytest.approx(1.043961, abs=1e-6)
+    assert np.linalg.eigvalsh(c.P).min() == pytest.approx(7500.0, rel=1e-9)
+
+
+def test_mpc_gradient_shift_matches_full_rebuild(qs):
+    """MPCSolver::setGradient: shift-by-one + last stage == full rebuild when the deque
+    advanced exactly one stage (MPCSolver.cpp:216-239), and short deques are padded."""
+    c = qs.mpc_constants(qs.MPCParams(horizon=6))
+    rng = np.random.default_rng(0)
+    ref = rng.normal(size=(9, 2))
+    up = rng.normal(size=2)
+    q0 = qs.mpc_gradient(c, ref, up)
+    q1_shift = qs.mpc_gradient(c, ref[1:], up, q_prev=q0, reset=False)
+    q1_full = qs.mpc_gradient(c, ref[1:], up)
+    assert np.array_equal(q1_shift, q1_full)
+    short = qs.mpc_gradient(c, ref[:3], up)
+    assert np.array_equal(short[4:6], short[12:14]) and np.array_equal(short[4:6], -c.Q @ ref[2])
+    assert np.array_equal(q0[c.n_x:c.n_x + 2], -c.R @ up) and not q0[c.n_x + 2:].any()
+
+
+def test_mpc_assemble_layout(qs):
+    c = qs.mpc_constants(qs.MPCParams(horizon=3))
+    hA = np.array([[1.0, 0], [0, 1], [-1, 0], [0, -1]])
+    hb = np.array([0.05, 0.025, 0.02, 0.025])
+    P, q, A, l, u = qs.mpc_assemble(c, [0.01, -0.02], np.zeros((4, 2)), [0, 0], hA, hb)
+    assert A.shape == (c.n_x + 4, c.n) and np.array_equal(A[c.n_x:, c.n_x:c.n_x + 2], hA)
+    assert not A[c.n_x:, :c.n_x].any() and not A[c.n_x:, c.n_x + 2:].any()      # only u0 is hull-constrained
+    assert np.array_equal(l[:2], [-0.01, 0.02]) and np.array_equal(u[:2], l[:2])
+    assert (l[c.n_x:] == -1e30).all() and np.array_equal(u[c.n_x:], hb)
+
+
+def test_config1_single_mpc_on_cpu(qs):
+    """BASELINE configs[0]: one MPC QP, N = 50, single support at identity, plumbing on CPU."""
+    c = qs.mpc_constants(qs.MPCParams())
+    hA = np.array([[1.0, 0], [0, 1], [-1, 0], [0, -1]])
+    hb = np.array([0.05, 0.025, 0.02, 0.025])
+    ref = np.stack([0.002 * np.arange(51), np.zeros(51)], 1)
+    r = qs.mpc_exact(c, [0.01, -0.005], ref, [0.0, 0.0], hA, hb)
+    z = r["z"]
+    assert np.abs(c.A_eq @ z - np.concatenate([[-0.01, 0.005], np.zeros(100)])).max() < 1e-12
+    assert r["margin"] >= -1e-12 and r["u0"].shape == (2,)
+    # a previous ZMP far ahead of the foot drags u0 onto the hull (R >> Q): the active row
+    # carries a positive multiplier
+    r2 = qs.mpc_exact(c, [0.01, -0.005], ref, [0.2, 0.0], hA, hb)
+    assert r2["active"] == [0] and r2["u0"][0] == pytest.approx(0.05, abs=1e-12) and r2["mu"][0] > 0
+
+
+def test_rot_error_small_angle(qs):
+    """unskew(0.5 (R Rd' - Rd R')) ~ rotation vector for small angles (Utils.cpp:22-27)."""
+    w = np.array([0.01, -0.02, 0.015])
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + K + 0.5 * K @ K
+    e = qs.rot_error(R, np.eye(3))
+    assert np.abs(e - w).max() < 1e-5
+    assert np.abs(qs.rot_error(R, R)).max() < 1e-15
+
+
+def test_ik_forms_differ_as_documented(qs, wca):
+    """Appendix B-13/14/15: osqp form has m = 38 with 23 zero rows, kappa = k_attFoot on the
+    neck term and the zero-twist rule; qpOASES form has variable bounds and kappa = 1."""
+    b = wca.synth.synth_ik_batch(4, seed=1)
+    p = qs.IKParams()
+    x = qs.ik_inputs_from_batch(b, 0)
+    P, q, A, l, u = qs.ik_assemble_osqp(p, x)
+    assert A.shape == (38, 29) and not A[15:].any() and np.array_equal(l[:15], u[:15])
+    assert np.array_equal(l[15:], -np.ones(23))
+    H, g, Aq, lb, ub, lbA, ubA = qs.ik_assemble_qpoases(p, x)
+    assert np.array_equal(H, P) and Aq.shape == (15, 29) and np.array_equal(lbA, ubA)
+    assert np.linalg.matrix_rank(H) == 26                     # rank 26/29
+    assert (ub[:6] == np.finfo(float).max).all() and np.array_equal(ub[6:], np.ones(23))
+    # gradient: neck term differs by exactly k_attFoot (= 2)
+    g_reg = np.zeros(29)
+    g_reg[6:] = -p.joint_reg_weights * p.joint_reg_gains * (p.q_reg - x.q)
+    assert np.allclose(q - g_reg, 2.0 * (g - g_reg), rtol=0, atol=1e-14)
+    # zero-twist rule: one foot of every synthetic robot is in stance (twist == 0)
+    stance_left = not x.twist_left.any()
+    rows = slice(0, 6) if stance_left else slice(6, 12)
+    assert not l[rows].any() and lbA[rows].any()
+
+
+@pytest.mark.parametrize("name", ["mpc_cfg2_b4096.npz", "mpc_stress_b1024.npz"])
+def test_oracle_reproduces_mpc_golden(qs, wca, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    kw = {"uprev_sigma": 0.04} if "stress" in name else {}
+    n = 96
+    b = wca.synth.synth_mpc_batch(n, seed=int(g["seed"]), **kw)
+    assert np.array_equal(b["x0"][:4], g["in_x0"]) and np.array_equal(b["hull_A"][:4], g["in_hull_A"])
+    c = qs.mpc_constants(qs.MPCParams())
+    for i in range(n):
+        r = qs.mpc_exact(c, b["x0"][i], b["ref"][i], b["u_prev"][i], b["hull_A"][i], b["hull_b"][i], int(b["hull_nc"][i]))
+        assert np.abs(r["u0"] - g["u0"][i]).max() < 1e-13
+        assert sum(1 << e for e in r["active"]) == int(g["active"][i])
+
+
+@pytest.mark.parametrize("name", ["ik_qpoases_v050_b1024.npz", "ik_qpoases_v030_b512.npz", "ik_osqp_b512.npz"])
+def test_oracle_reproduces_ik_golden(qs, wca, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    n = 96
+    b = wca.synth.synth_ik_batch(n, seed=int(g["seed"]))
+    assert np.array_equal(b["q"][:2], g["in_q"]) and np.array_equal(b["J_com"][:2], g["in_J_com"])
+    p = qs.IKParams(v_max=float(g["v_max"]) * np.ones(23))
+    for i in range(n):
+        r = qs.ik_exact(p, qs.ik_inputs_from_batch(b, i), str(g["form"]))
+        assert np.abs(r["dq"] - g["dq"][i]).max() < 1e-12
+        assert sum(1 << j for j in r["lower"]) == int(g["active_lower"][i])
+        assert sum(1 << j for j in r["upper"]) == int(g["active_upper"][i])
+
+
+def test_exact_oracle_flags_infeasible(qs, wca):
+    b = wca.synth.synth_ik_batch(1, seed=2)
+    with pytest.raises(qs.QPInfeasible):
+        qs.ik_exact(qs.IKParams(v_max=1e-3 * np.ones(23)), qs.ik_inputs_from_batch(b, 0), "qpoases")
+
+
+# ---- the C restatement (OSQP algorithm, dense active set) against the exact optimum -------
+def test_c_osqp_restatement_reaches_the_optimum_within_its_eps(qs, wca):
+    """Secondary parity (SURVEY §7 'hard parts'): the OSQP-default-settings restatement agrees
+    with the exact optimum within OSQP's own eps = 1e-3, and to 1e-7 when run tight."""
+    from oracle import c_oracle as co
+    mp = qs.MPCParams()
+    c = qs.mpc_constants(mp)
+    b = wca.synth.synth_mpc_batch(24, seed=77, uprev_sigma=0.04)
+    u0, iters, status = co.mpc_batch_osqp(mp, b, nthreads=2)
+    assert (status == 0).all() and iters.max() <= 4000
+    ex = np.array([qs.mpc_exact(c, b["x0"][i], b["ref"][i], b["u_prev"][i], b["hull_A"][i], b["hull_b"][i],
+                                int(b["hull_nc"][i]))["u0"] for i in range(24)])
+    assert np.abs(u0 - ex).max() < 1e-3
+    P, q, A, l, u = qs.mpc_assemble(c, b["x0"][0], b["ref"][0], b["u_prev"][0],
+                                    b["hull_A"][0][:b["hull_nc"][0]], b["hull_b"][0][:b["hull_nc"][0]])
+    x, it, rc = co.osqp_dense(P, q, A, l, u, eps_abs=1e-10, eps_rel=1e-10, max_iter=20000)
+    assert rc == 0 and np.abs(x[102:104] - ex[0]).max() < 1e-7
+
+
+@pytest.mark.parametrize("form,vmax", [("qpoases", 0.5), ("qpoases", 0.3), ("osqp", 1.0)])
+def test_c_ik_restatement(qs, wca, form, vmax):
+    from oracle import c_oracle as co
+    b = wca.synth.synth_ik_batch(48, seed=4321)
+    ip = qs.IKParams(v_max=vmax * np.ones(23))
+    dq, status, lo, up, iters = co.ik_batch(ip, b, form, nthreads=2)
+    assert (status == 0).all()
+    tol = 1e-3 if form == "osqp" else 1e-12
+    for i in range(48):
+        r = qs.ik_exact(ip, qs.ik_inputs_from_batch(b, i), form)
+        assert np.abs(dq[i] - r["dq"]).max() < tol
+        if form == "qpoases":
+            assert int(lo[i]) == sum(1 << j for j in r["lower"]) and int(up[i]) == sum(1 << j for j in r["upper"])

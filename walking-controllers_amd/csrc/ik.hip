@@ -420,7 +420,9 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 zbuf[i] = z;
                 wcqp::wave_lds_fence();
                 const double nz = sig * zbuf[p];
-                const double t2 = nz > 1e-12 * ppp ? s / nz : inf;
+                // a full active set (nW == n - meq) leaves no direction: p is then dependent by
+                // construction; otherwise dependence shows as a vanishing Schur complement
+                const double t2 = (nW < KMAX && nz > 1e-10 * ppp) ? s / nz : inf;
                 double t1 = inf;
                 int jd = -1;
 #pragma unroll 1
@@ -458,6 +460,19 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 wcqp::wave_lds_fence();
             }
             wcqp::wave_lds_fence();
+        }
+        // certificate: every bound holds and every active bound is tight, else the walk
+        // lost accuracy (near-dependent working set) and the answer must not read SOLVED
+        {
+            const double dev = !(var && i >= 6) ? 0.0
+                             : (in_w ? fabs(nu - (my_sig > 0.0 ? hi : lo)) : fmax(nu - hi, lo - nu));
+            vbuf[i] = dev == dev ? dev : inf;
+            wcqp::wave_lds_fence();
+            double worst = 0.0;
+#pragma unroll 1
+            for (int j = 6; j < kNV; ++j) worst = fmax(worst, vbuf[j]);
+            if (st_code == WCQP_STATUS_SOLVED && worst > 1e-9) st_code = WCQP_STATUS_NUMERIC;
+            if (st_code == WCQP_STATUS_SOLVED && in_w) nu = my_sig > 0.0 ? hi : lo;
         }
     }
 
