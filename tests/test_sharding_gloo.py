@@ -1,0 +1,104 @@
+"""
+N > 1 path on CPU: two processes, gloo backend.  The per-shard solver here is the C oracle
+(tests may use it as the checker's stand-in; on a GPU box the same plumbing wraps the HIP
+path — see test_gpu_sharded_equals_single below).  What is verified is the sharding
+contract: contiguous block split, no data-path collective, optional scatter/gather, and
+SHARD-COUNT INVARIANCE — the gathered result is bitwise the single-process result.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, exchange, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import walking_controllers_amd as wca
+    from oracle import c_oracle as co, qp_spec as qs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ip = qs.IKParams(v_max=0.4 * np.ones(23))
+    keys = ("J_left", "J_right", "J_neck", "J_com", "q", "state")
+
+    def make(first, count):
+        b = wca.synth.synth_ik_batch(count, seed=21, first=first)
+        return {k: b[k] for k in keys}
+
+    def solve(inp):
+        dq, status, lo, up, _ = co.ik_batch(ip, inp, "qpoases", nthreads=1)
+        return {"dq": dq, "status": status, "lo": lo.astype(np.int64), "up": up.astype(np.int64)}
+
+    out = wca.sharding.solve_sharded(dist, 64, make, solve, exchange=exchange)
+    if rank == 0:
+        q.put({k: v for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", [False, True])
+def test_world_size_2_gloo_matches_single_process(exchange):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import walking_controllers_amd as wca
+    from oracle import c_oracle as co, qp_spec as qs
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, exchange, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b = wca.synth.synth_ik_batch(64, seed=21)
+    dq, status, lo, up, _ = co.ik_batch(qs.IKParams(v_max=0.4 * np.ones(23)), b, "qpoases", nthreads=1)
+    assert np.array_equal(got["dq"], dq) and np.array_equal(got["status"], status)       # bitwise
+    assert np.array_equal(got["lo"], lo.astype(np.int64)) and np.array_equal(got["up"], up.astype(np.int64))
+
+
+def test_shard_ranges_cover_the_batch():
+    sys.path.insert(0, ROOT)
+    import walking_controllers_amd as wca
+    for B, G in ((65536, 8), (4096, 2), (10, 4), (7, 8)):
+        seen = []
+        for r in range(G):
+            f, c = wca.sharding.shard_range(B, G, r)
+            seen += list(range(f, f + c))
+        assert seen == list(range(B))
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_equals_single(wca):
+    """On the GPU box: solving two half-batches separately (what two ranks would do) gives
+    bitwise the rows of the full-batch solve — per-instance results do not depend on which
+    shard, wave or lane half an instance lands in."""
+    B = 1024
+    full_i = wca.synth.synth_ik_batch(B, seed=5)
+    full_m = wca.synth.synth_mpc_batch(B, seed=6, uprev_sigma=0.04)
+    ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4)
+    mpc = wca.MpcSolver()
+    ki = ("J_left", "J_right", "J_neck", "J_com", "q", "state")
+    km = ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc")
+    one_i = ik.solve_host(*[full_i[k] for k in ki])
+    one_m = mpc.solve_host(*[full_m[k] for k in km])
+    for world in (2, 8):
+        parts_i, parts_m = [], []
+        for r in range(world):
+            f, c = wca.sharding.shard_range(B, world, r)
+            si = wca.synth.synth_ik_batch(c, seed=5, first=f)
+            sm = wca.synth.synth_mpc_batch(c, seed=6, first=f, uprev_sigma=0.04)
+            parts_i.append(ik.solve_host(*[si[k] for k in ki]))
+            parts_m.append(mpc.solve_host(*[sm[k] for k in km]))
+        assert np.array_equal(np.concatenate([p["dq"] for p in parts_i]), one_i["dq"])
+        assert np.array_equal(np.concatenate([p["active_upper"] for p in parts_i]), one_i["active_upper"])
+        assert np.array_equal(np.concatenate([p["u0"] for p in parts_m]), one_m["u0"])

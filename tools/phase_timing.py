@@ -1,0 +1,25 @@
+"""Diagnostic: time the IK kernel of the library named by WCQP_LIB_PATH (phase-stop builds)."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import walking_controllers_amd as wca
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+vmax = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+dev = torch.device("cuda", 0)
+ib = wca.synth.synth_ik_batch(B, seed=4321)
+d = {k: torch.from_numpy(ib[k]).to(dev) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")}
+dq = torch.zeros(B, 23, dtype=torch.float64, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
+lo = torch.zeros_like(st); up = torch.zeros_like(st); it = torch.zeros_like(st)
+ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax)
+sp = torch.cuda.current_stream().cuda_stream
+def run():
+    ik.solve_device(B, d["J_left"].data_ptr(), d["J_right"].data_ptr(), d["J_neck"].data_ptr(), d["J_com"].data_ptr(),
+                    d["q"].data_ptr(), d["state"].data_ptr(), dq.data_ptr(), st.data_ptr(), lo.data_ptr(), up.data_ptr(), 0, it.data_ptr(), sp)
+for _ in range(5): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 30
+e0.record()
+for _ in range(n): run()
+e1.record(); torch.cuda.synchronize()
+print(json.dumps({"lib": os.path.basename(os.environ.get("WCQP_LIB_PATH", "libwcqp.so")), "B": B, "vmax": vmax, "ik_ms": e0.elapsed_time(e1) / n}))

@@ -6,11 +6,12 @@ Jacobian QP-IK of lia2790/walking-controllers.
               reference's WalkingController / WalkingQPIK interfaces
   capi.py     ctypes binding of the C ABI
   synth.py    synthetic iCub-shaped workloads
+  sharding.py contiguous block split of the batch over ranks (+ optional scatter/gather)
 
 The directory name carries a hyphen, so import it through the repo-root shim:
     import walking_controllers_amd as wca
 """
-from . import capi, synth  # noqa: F401
+from . import capi, sharding, synth  # noqa: F401
 from .capi import (IkSolver, MpcSolver, WcqpError, IK_FORM_OSQP, IK_FORM_QPOASES,  # noqa: F401
                    STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_OUTSIDE_HULL,
                    STATUS_NUMERIC, device_count)

@@ -15,7 +15,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwcqp.so")
+LIB_PATH = os.environ.get("WCQP_LIB_PATH") or os.path.join(_HERE, "libwcqp.so")   # override: diagnostic builds only
 
 WCQP_OK = 0
 STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_OUTSIDE_HULL, STATUS_NUMERIC = range(5)

@@ -52,32 +52,36 @@ struct IkLayout {
     static constexpr int MEQ = USE_COM ? 15 : 12;       // equality rows
     static constexpr int NC1 = MEQ + 1;                 // columns of G+ = [A' g~]
     static constexpr int KMAX = kNV - MEQ;              // most bounds that can be active at once
-    static constexpr int LDS_S = 16;                    // leading dim of Sinv rows
-    static constexpr int LDL = KMAX + 1;
+    static constexpr int LDS_S = MEQ + (MEQ & 1);       // leading dim of Sinv rows
+    static constexpr int LDL = KMAX;
+    static constexpr int TCS = 30;                      // stride of one stored column of P (29 live lanes)
     // ---- per-instance LDS map (doubles) ----
     static constexpr int OFF_CR = 0;                    // [18][kLD]   phases 1-5
     static constexpr int OFF_GM = OFF_CR + kRows * kLD; // [29][kLDG]  phases 4-5
     static constexpr int END_MAT = OFF_GM + kNV * kLDG;
     // phase 6 reuses the matrix area
-    static constexpr int OFF_TC = 0;                    // [KMAX][32]
-    static constexpr int OFF_SV = OFF_TC + KMAX * 32;   // [MEQ][LDS_S]
+    static constexpr int OFF_TC = 0;                    // [KMAX][TCS]
+    static constexpr int OFF_SV = OFF_TC + KMAX * TCS;  // [MEQ][LDS_S]
     static constexpr int OFF_LK = OFF_SV + MEQ * LDS_S; // [KMAX][LDL]
-    static constexpr int END_AS = OFF_LK + KMAX * LDL;
+    static constexpr int OFF_GROW = OFF_LK + KMAX * LDL; // [16] one row of G
+    static constexpr int OFF_R = OFF_GROW + 16;         // [20] dual step r
+    static constexpr int OFF_MU = OFF_R + 20;           // [20] multipliers of W
+    static constexpr int OFF_WS = OFF_MU + 20;          // [20] signs of W
+    static constexpr int OFF_WI = OFF_WS + 20;          // [20] ints (stored in doubles' space)
+    static constexpr int END_AS = OFF_WI + 20;
     static_assert(END_AS <= END_MAT, "active-set scratch must fit in the dead matrix area");
     static constexpr int OFF_ST = END_MAT;              // [112] state 87 + q 23; later 4 x [32] vectors
     static constexpr int OFF_V0 = OFF_ST;               // vbuf   (violations)
     static constexpr int OFF_V1 = OFF_ST + 32;          // sgbuf / zbuf
     static constexpr int OFF_V2 = OFF_ST + 64;          // tpbuf
     static constexpr int OFF_V3 = OFF_ST + 96;          // rowbuf [32]
-    static constexpr int OFF_COL = OFF_ST + 128;        // [32] published column
-    static constexpr int OFF_B = OFF_COL + 32;          // [16] task rhs
+    static constexpr int OFF_COL = OFF_ST;              // [2][32] published column, double-buffered; the sweeps
+                                                        // run after the state block is dead and before phase 6
+    static constexpr int OFF_B = OFF_ST + 128;          // [16] task rhs
     static constexpr int OFF_LAM = OFF_B + 16;          // [16] multipliers / rhs
-    static constexpr int OFF_GROW = OFF_LAM + 16;       // [16] one row of G
-    static constexpr int OFF_R = OFF_GROW + 16;         // [20] dual step r
-    static constexpr int OFF_MU = OFF_R + 20;           // [20] multipliers of W
-    static constexpr int OFF_WS = OFF_MU + 20;          // [20] signs of W
-    static constexpr int OFF_WI = OFF_WS + 20;          // [20] ints (stored as doubles' space)
-    static constexpr int PER_INST = ((OFF_WI + 20) + 1) & ~1;
+    static constexpr int PER_INST = ((OFF_LAM + 16) + 1) & ~1;
+    // two instances per workgroup, 8 workgroups per CU (2 waves per SIMD) must fit in 160 KiB
+    static_assert(2 * PER_INST * 8 <= 20480, "LDS budget: 8 workgroups per CU");
 };
 
 // rotation error component k of unskew(0.5 (E - E')), E = R Rd'     Utils.cpp:22-27
@@ -88,32 +92,57 @@ __device__ __forceinline__ double rot_err(const double* R, const double* Rd, int
     return 0.5 * (eab - eba);
 }
 
+// Broadcast of lane `SRC` of each 32-lane group to every lane of that group: ds_swizzle in
+// bit-mask mode (and = 0, or = SRC, xor = 0) moves data through the LDS crossbar without
+// touching LDS memory, so no write -> read round trip is needed.
+template <int SRC>
+__device__ __forceinline__ double group_bcast(double v) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (SRC & 31) << 5);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (SRC & 31) << 5);
+    return __hiloint2double(hi, lo);
+}
+
 // Symmetric sweep over pivots 0..SZ-1 of the matrix whose row i sits in `row` of lane i.
 // On exit row = -(A^-1) row.  Lanes >= SZ must hold zero rows (they act as padding).
+//
+// Software-pipelined: the only serial chain is pivot -> reciprocal -> multiplier -> next
+// pivot, and it runs entirely in registers (two crossbar broadcasts per step): column k+1
+// is updated first and its pivot broadcast at once, while the bulk of step k's rank-1
+// update waits for the published column k to come back from LDS.  `col` is double-buffered
+// (2 x 32 doubles) so step k+1's publish never races step k's reads.
+template <int SZ, int K, int NR>
+__device__ __forceinline__ void sweep_step(double (&row)[NR], double* col, int i, double& piv, bool& ok) {
+    double* cb = col + 32 * (K & 1);
+    const double ck = row[K];
+    cb[i] = ck;                                        // column K == row K (symmetry)
+    ok = ok && (piv > 0.0);
+    const double d = wcqp::fast_rcp(piv);
+    const double f0 = ck * d;
+    // lane K holds row K == the column itself: row - (1-d) col = d col, so one multiplier
+    // serves every lane and no per-element select is needed
+    const double f = (i == K) ? (1.0 - d) : f0;
+    if constexpr (K + 1 < SZ) {
+        const double cn = group_bcast<K + 1>(ck);      // M[K+1][K]
+        row[K + 1] = fma(-f, cn, row[K + 1]);
+        piv = group_bcast<K + 1>(row[K + 1]);          // next pivot, off the LDS round trip
+    }
+    wcqp::wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < SZ; j += 2) {
+        const double2 c2 = *reinterpret_cast<const double2*>(cb + j);
+        if (j != K && j != K + 1) row[j] = fma(-f, c2.x, row[j]);
+        if (j + 1 < SZ && j + 1 != K && j + 1 != K + 1) row[j + 1] = fma(-f, c2.y, row[j + 1]);
+    }
+    row[K] = (i == K) ? -d : f0;
+    if constexpr (K + 1 < SZ) sweep_step<SZ, K + 1, NR>(row, col, i, piv, ok);
+}
+
 template <int SZ, int NR>
 __device__ __forceinline__ bool sweep_rows(double (&row)[NR], double* col, int i) {
     bool ok = true;
-#pragma unroll
-    for (int k = 0; k < SZ; ++k) {
-        const double ck = row[k];
-        col[i] = ck;                                   // column k == row k (symmetry)
-        wcqp::wave_lds_fence();
-        const double pk = col[k];
-        ok = ok && (pk > 0.0);
-        const double d = wcqp::fast_rcp(pk);
-        const double f0 = ck * d;
-        // lane k holds row k == the column itself: row - (1-d) col = d col, so one
-        // multiplier serves every lane and no per-element select is needed
-        const double f = (i == k) ? (1.0 - d) : f0;
-#pragma unroll
-        for (int j = 0; j < SZ; j += 2) {
-            const double2 c2 = *reinterpret_cast<const double2*>(col + j);
-            if (j != k) row[j] = fma(-f, c2.x, row[j]);
-            if (j + 1 < SZ && j + 1 != k) row[j + 1] = fma(-f, c2.y, row[j + 1]);
-        }
-        row[k] = (i == k) ? -d : f0;
-        wcqp::wave_lds_fence();
-    }
+    double piv = group_bcast<0>(row[0]);
+    sweep_step<SZ, 0, NR>(row, col, i, piv, ok);
+    wcqp::wave_lds_fence();
     return ok;
 }
 
@@ -185,6 +214,9 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
     wcqp::wave_lds_fence();
 
+#if defined(WCQP_IK_PHASE_STOP) && WCQP_IK_PHASE_STOP == 1   /* diagnostic timing builds only (tools/phase_timing.sh) */
+    { double accx = 0.0; _Pragma("unroll") for (int r = 0; r < kRows; ++r) accx += cl[r];  if (live && var) dq_out[inst * kDof + (i % kDof)] = accx; return; }
+#endif
     // ---------------- phase 1: task rhs b (lane r < MEQ) and gradient g~ ----------------
     const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
     double b_mine = 0.0;
@@ -228,6 +260,9 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         gt = g - prm->rho * atb;
     }
 
+#if defined(WCQP_IK_PHASE_STOP) && WCQP_IK_PHASE_STOP == 2   /* diagnostic timing builds only (tools/phase_timing.sh) */
+    { double accx = 0.0; _Pragma("unroll") for (int r = 0; r < kRows; ++r) accx += cl[r]; accx += gt + b_mine; if (live && var) dq_out[inst * kDof + (i % kDof)] = accx; return; }
+#endif
     // ---------------- phase 2: M rows ---------------------------------------------------
     double Mr[kNV];
 #pragma unroll
@@ -250,11 +285,17 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         for (int j = 0; j < kNV; ++j) Mr[j] += (i == j) ? lam_i : 0.0;
     }
 
+#if defined(WCQP_IK_PHASE_STOP) && WCQP_IK_PHASE_STOP == 3   /* diagnostic timing builds only (tools/phase_timing.sh) */
+    { double accx = 0.0; _Pragma("unroll") for (int r = 0; r < kRows; ++r) accx += cl[r]; accx += gt + b_mine; _Pragma("unroll") for (int j = 0; j < kNV; ++j) accx += Mr[j]; if (live && var) dq_out[inst * kDof + (i % kDof)] = accx; return; }
+#endif
     // ---------------- phase 3: Minv -----------------------------------------------------
     bool ok = sweep_rows<kNV>(Mr, col, i);
 #pragma unroll
     for (int j = 0; j < kNV; ++j) Mr[j] = -Mr[j];
 
+#if defined(WCQP_IK_PHASE_STOP) && WCQP_IK_PHASE_STOP == 4   /* diagnostic timing builds only (tools/phase_timing.sh) */
+    { double accx = 0.0; _Pragma("unroll") for (int r = 0; r < kRows; ++r) accx += cl[r]; accx += gt + b_mine; _Pragma("unroll") for (int j = 0; j < kNV; ++j) accx += Mr[j]; if (live && var) dq_out[inst * kDof + (i % kDof)] = accx; return; }
+#endif
     // ---------------- phase 4: G+ = Minv [A' g~] ----------------------------------------
     if (i < kLD) Cr[MEQ * kLD + i] = var ? gt : 0.0;     // row MEQ of C+ := g~ (cost rows are dead)
     wcqp::wave_lds_fence();
@@ -277,6 +318,9 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
     wcqp::wave_lds_fence();
 
+#if defined(WCQP_IK_PHASE_STOP) && WCQP_IK_PHASE_STOP == 5   /* diagnostic timing builds only (tools/phase_timing.sh) */
+    { double accx = 0.0; _Pragma("unroll") for (int r = 0; r < kRows; ++r) accx += cl[r]; accx += gt + b_mine; _Pragma("unroll") for (int j = 0; j < kNV; ++j) accx += Mr[j]; _Pragma("unroll") for (int c = 0; c < NC1; ++c) accx += Gr[c]; if (live && var) dq_out[inst * kDof + (i % kDof)] = accx; return; }
+#endif
     // ---------------- phase 5: S+ rows, Sinv, lambda, equality optimum -------------------
     double Sr[NC1];
     {
@@ -313,6 +357,9 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
     for (int c = 0; c < MEQ; ++c) nu = fma(-Gr[c], lamv[c], nu);
 
+#if defined(WCQP_IK_PHASE_STOP) && WCQP_IK_PHASE_STOP == 6   /* diagnostic timing builds only (tools/phase_timing.sh) */
+    { double accx = 0.0; _Pragma("unroll") for (int r = 0; r < kRows; ++r) accx += cl[r]; accx += nu; _Pragma("unroll") for (int j = 0; j < kNV; ++j) accx += Mr[j]; _Pragma("unroll") for (int c = 0; c < NC1; ++c) accx += Gr[c] + Sr[c]; if (live && var) dq_out[inst * kDof + (i % kDof)] = accx; return; }
+#endif
     // ---------------- phase 6: joint-velocity bounds (qpOASES form) ----------------------
     int st_code = ok ? WCQP_STATUS_SOLVED : WCQP_STATUS_NUMERIC;
     int it = 0;
@@ -395,7 +442,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                     const double sa = Wsg[a];
 #pragma unroll 1
                     for (int bb = 0; bb <= a; ++bb) {
-                        double sum = sa * Tc[bb * 32 + wa];
+                        double sum = sa * Tc[bb * L::TCS + wa];
 #pragma unroll 1
                         for (int c = 0; c < bb; ++c) sum -= Lk[a * L::LDL + c] * Lk[bb * L::LDL + c];
                         if (a == bb) Lk[a * L::LDL + a] = sqrt(fmax(sum, 1e-300));
@@ -416,7 +463,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 // primal step z = tp - sum_a r_a Tc[a]
                 double z = tp;
 #pragma unroll 1
-                for (int a = 0; a < nW; ++a) z = fma(-rvec[a], Tc[a * 32 + i], z);
+                for (int a = 0; a < nW; ++a) z = fma(-rvec[a], Tc[a * L::TCS + (var ? i : 0)], z);
                 zbuf[i] = z;
                 wcqp::wave_lds_fence();
                 const double nz = sig * zbuf[p];
@@ -441,7 +488,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 mu_p += t;
                 s -= t * nz;
                 if (t2 <= t1) {                          // full step: p joins W
-                    Tc[nW * 32 + i] = tp;
+                    if (var) Tc[nW * L::TCS + i] = tp;
                     Wi[nW] = p; Wsg[nW] = sig; Wmu[nW] = mu_p;
                     if (i == p) { in_w = true; my_sig = sig; }
                     ++nW;
@@ -451,7 +498,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 if (i == Wi[jd]) { in_w = false; my_sig = 0.0; }
 #pragma unroll 1
                 for (int a = jd; a < nW - 1; ++a) {
-                    Tc[a * 32 + i] = Tc[(a + 1) * 32 + i];
+                    if (var) Tc[a * L::TCS + i] = Tc[(a + 1) * L::TCS + i];
                     const int w1 = Wi[a + 1]; const double s1 = Wsg[a + 1], m1 = Wmu[a + 1];
                     Wi[a] = w1; Wsg[a] = s1; Wmu[a] = m1;
                 }
