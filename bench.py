@@ -207,11 +207,12 @@ def main():
         "solved": {"ik": n_ok_ik, "mpc": n_ok_mpc, "of": B, "ik_mean_active_set_changes": ik_iters,
                    "ik_frac_with_active_bounds": frac_active},
     }
+    # HBM bytes per launch from the PMC passes of tools/pmc/collect.sh (committed summary)
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
-            tr = json.load(open(traffic_file))
-            if int(tr.get("batch", -1)) == B:
+            tr = json.load(open(traffic_file)).get("per_batch", {}).get(str(B))
+            if tr:
                 out["roofline"]["traffic"] = tr.get("ik_hbm_bytes_per_launch")
         except Exception:
             pass
@@ -233,6 +234,12 @@ def cpu_baseline(mb, ib, args):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    try:                                                  # honour a cgroup CPU quota if there is one
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            avail = min(avail, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
     cores = max(1, min(co.num_threads(), avail))
     mp = qs.MPCParams()
     ipar = qs.IKParams(v_max=args.ik_vmax * np.ones(23))

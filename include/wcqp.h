@@ -194,6 +194,64 @@ int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
                        uint32_t* active_lower, uint32_t* active_upper,
                        double* foot_err, int32_t* iters);
 
+/* =====================================================================================
+ * Device-resident tick pipeline — BASELINE configs 4/5 and SURVEY.md §8f-1/2: the call
+ * order of WalkingModule::updateModule around the two solvers (WM/src/WalkingModule.cpp:
+ * 578-745) for a batch of synthetic robots, kept entirely on the GPU:
+ *   pre   contact pair of this tick, hull rows swapped on change (= setConvexHullConstraint,
+ *         cold start of that instance), LIPM reference (StableDCMModel.cpp:63-90)
+ *   MPC   window [t, t+N] of the per-instance DCM reference trajectory (the deque that
+ *         advances one stage per tick, WalkingModule.cpp:35-96), x0 = measured DCM,
+ *         u_prev = previous output (MPCSolver.cpp:244-245)
+ *   glue  ZMP-CoM law + integrator (WalkingZMPController.cpp:146-173) -> desired CoM position /
+ *         velocity into the IK pose block (WalkingModule.cpp:686-695); synthetic LIPM plant
+ *   IK    joint velocities
+ *   post  q <- Integrator(dq) (WalkingModule.cpp:741-744)
+ * The six launches of a tick are captured ONCE in a hipGraph and replayed per tick
+ * (`use_graph`), with the tick index living in device memory.
+ * ===================================================================================== */
+typedef struct wcqp_tick_params {
+    int32_t batch;              /* instances on this device                                   */
+    int32_t first;              /* global index of instance 0 (disturbance stream)             */
+    int32_t max_ticks;          /* trajectories hold max_ticks + horizon + 1 stages            */
+    int32_t log_ticks;          /* > 0: keep u0/dq of the first log_ticks ticks for parity     */
+    int32_t step_ticks, ds_ticks;
+    double  k_com, k_zmp;       /* zmpControllerParams.ini:7-8                                 */
+    double  noise;              /* amplitude of the bounded DCM disturbance                    */
+    uint64_t seed;
+    wcqp_mpc_params mpc;
+    wcqp_ik_params ik;
+} wcqp_tick_params;
+
+typedef struct wcqp_tick_inputs {   /* HOST pointers, copied at upload */
+    const double* ref_traj;     /* [B][max_ticks+N+1][2]                                      */
+    const double* hull_tab_A;   /* [B][3][8][2]  rows for {left, right, both} in contact       */
+    const double* hull_tab_b;   /* [B][3][8]                                                   */
+    const int32_t* hull_tab_nc; /* [B][3]                                                      */
+    const int32_t* phase0;      /* [B] offset into the step cycle                              */
+    const double* J_left; const double* J_right; const double* J_neck; const double* J_com;
+    const double* state0;       /* [B][87] poses; CoM entries and twists are rewritten per tick */
+    const double* swing_twist;  /* [B][6] desired twist of whichever foot is in the air        */
+    const double* q0;           /* [B][dof]                                                    */
+    const double* dcm0; const double* com0; const double* u_init;   /* [B][2] each             */
+} wcqp_tick_inputs;
+
+typedef struct wcqp_tick_outputs {  /* HOST pointers, any may be NULL */
+    double* u0_log;             /* [log_ticks][B][2]                                           */
+    double* dq_log;             /* [log_ticks][B][dof]                                         */
+    double* q_des;              /* [B][dof]                                                    */
+    double* dcm; double* com;   /* [B][2]                                                      */
+    int64_t* mpc_fail; int64_t* ik_fail;   /* [B] ticks whose QP did not end SOLVED            */
+    int32_t* tick;              /* ticks executed so far                                       */
+} wcqp_tick_outputs;
+
+typedef struct wcqp_tick_s* wcqp_tick_t;
+int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out);
+int wcqp_tick_destroy(wcqp_tick_t h);
+int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in);                 /* also rewinds to tick 0 */
+int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream); /* enqueue only  */
+int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out);             /* synchronises     */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,141 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the per-tick call order of WalkingModule::updateModule around the two
+solvers (WM/src/WalkingModule.cpp:578-745) for a batch of synthetic robots, using the exact
+solvers of oracle/qp_spec.py.  It is the checker of the device-resident tick pipeline
+(walking-controllers_amd/csrc/tick.hip, BASELINE configs 4 and 5).
+
+What is restated from the reference (and where):
+  LIPM reference    v = -omega (c - dcm_des), c <- Integrator(v)      WM/src/StableDCMModel.cpp:63-90
+  MPC               setConvexHullConstraint / setFeedback / setReferenceSignal / solve
+                                                                      WM/src/WalkingModule.cpp:604-636
+  ZMP-CoM law       v* = kCoM (c_des - c) - kZMP (zmp_des - zmp) + v_des, p* <- Integrator(v*)
+                                                                      WM/src/WalkingZMPController.cpp:146-173
+  IK                desired CoM = (p*, h), desired CoM velocity = (v*, 0)
+                                                                      WM/src/WalkingModule.cpp:686-695, 367-425
+  joint integration q <- Integrator(dq)                               WM/src/WalkingModule.cpp:741-744
+  reference deque   advances one stage per tick                       WM/src/WalkingModule.cpp:35-96
+  contact change    => new MPCSolver (cold start)                     …PredictiveController.cpp:415-420
+
+Declared choices: iCub::ctrl::Integrator is upstream; it is restated
+as the trapezoidal (Tustin) rule y += Ts/2 (x + x_prev), x_prev(0) = 0.  Gains are the
+"walking" gains of app/robots/iCubGazeboV2_5/zmpControllerParams.ini:7-8 (kZMP 3.0, kCoM 9.0,
+no gain scheduling).  The robot itself is synthetic (there is no simulator in scope): the
+measured DCM follows the LIPM  xi+ = a xi + b u0 + w  with a bounded uniform disturbance w
+drawn from the same counter-based mixer as the workloads, the measured CoM follows
+c+ = c + dT (-omega (c - xi)), the measured ZMP is the previous command, measured joint
+positions equal the desired ones, Jacobians are constant per instance.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from . import qp_spec as qs
+
+_M1 = np.uint64(0x9E3779B97F4A7C15)
+_M2 = np.uint64(0xBF58476D1CE4E5B9)
+_M3 = np.uint64(0x94D049BB133111EB)
+
+
+def _mix(x):
+    x = np.asarray(x, dtype=np.uint64).copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30); x *= _M2
+        x ^= x >> np.uint64(27); x *= _M3
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def disturbance(seed: int, inst: np.ndarray, tick: int, axis: int) -> np.ndarray:
+    """uniform in [-1, 1): the same integer mixer the device kernel runs (no transcendental,
+    so host and device agree bit for bit)."""
+    with np.errstate(over="ignore"):
+        base = _mix(np.asarray(inst, np.uint64) * _M1 + np.uint64(seed))
+        h = _mix(base + (np.uint64(2 * tick + axis) + np.uint64(1)) * _M3)
+    return (h >> np.uint64(11)).astype(np.float64) * (2.0 / 9007199254740992.0) - 1.0
+
+
+@dataclasses.dataclass
+class TickParams:
+    horizon: int = 50
+    dT: float = 0.01
+    com_height: float = 0.53
+    gravity: float = 9.81
+    k_com: float = 9.0          # zmpControllerParams.ini:8  kCoM_walking
+    k_zmp: float = 3.0          # zmpControllerParams.ini:7  kZMP_walking
+    step_ticks: int = 180       # synthetic gait: 1.8 s per step, of which
+    ds_ticks: int = 110         # 1.1 s double support (the shipped 0.9 s step
+                                # diverges under a linear ZMP hand-over with the shipped MPC weights)
+    noise: float = 1e-4         # amplitude of the DCM disturbance [m]
+    seed: int = 99
+
+
+def contact_code(t: int, phase0: np.ndarray, p: TickParams) -> np.ndarray:
+    """0 = left only, 1 = right only, 2 = both."""
+    cyc = (t + phase0) % (2 * p.step_ticks)
+    s = cyc % p.step_ticks
+    side = cyc // p.step_ticks
+    return np.where(s < p.ds_ticks, 2, side).astype(np.int32)
+
+
+def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, ik_form: str = "qpoases"):
+    """data: the arrays of walking-controllers_amd/synth.py::synth_tick_batch.  Returns the
+    per-tick logs u0[T][B][2], dq[T][B][23] and the final states."""
+    B = data["q0"].shape[0]
+    N = p.horizon
+    mp = qs.MPCParams(horizon=N, sampling_time=p.dT, com_height=p.com_height, gravity=p.gravity)
+    c = qs.mpc_constants(mp)
+    omega = np.sqrt(p.gravity / p.com_height)
+    inst = np.arange(B, dtype=np.uint64) + np.uint64(data.get("first", 0))
+    dcm = data["dcm0"].copy(); com = data["com0"].copy(); zmp_meas = data["u_init"].copy()
+    u_prev = data["u_init"].copy()
+    c_ref = data["com0"].copy(); v_ref_prev = np.zeros((B, 2))
+    p_star = data["com0"].copy(); v_star_prev = np.zeros((B, 2))
+    q_des = data["q0"].copy(); dq_prev = np.zeros((B, 23))
+    u0_log = np.zeros((n_ticks, B, 2)); dq_log = np.zeros((n_ticks, B, 23))
+    mpc_fail = np.zeros(B, np.int64); ik_fail = np.zeros(B, np.int64)
+    for t in range(n_ticks):
+        code = contact_code(t, data["phase0"], p)
+        r_t = data["ref_traj"][:, t, :]
+        # LIPM reference (StableDCMModel.cpp:63-90)
+        v_ref = -omega * (c_ref - r_t)
+        c_ref = c_ref + 0.5 * p.dT * (v_ref + v_ref_prev); v_ref_prev = v_ref
+        u0 = np.zeros((B, 2))
+        for i in range(B):
+            k = int(code[i])
+            nc = int(data["hull_tab_nc"][i, k])
+            try:
+                r = qs.mpc_exact(c, dcm[i], data["ref_traj"][i, t:t + N + 1], u_prev[i],
+                                 data["hull_tab_A"][i, k], data["hull_tab_b"][i, k], nc)
+                u0[i] = r["u0"]
+            except qs.QPOracleError:
+                u0[i] = u_prev[i]; mpc_fail[i] += 1
+        # ZMP-CoM law (WalkingZMPController.cpp:146-173)
+        v_star = p.k_com * (c_ref - com) - p.k_zmp * (u0 - zmp_meas) + v_ref
+        p_star = p_star + 0.5 * p.dT * (v_star + v_star_prev); v_star_prev = v_star
+        dq = np.zeros((B, 23))
+        for i in range(B):
+            s = data["state0"][i].copy()
+            s[66:68] = com[i]; s[68] = p.com_height
+            s[69:71] = p_star[i]; s[71] = p.com_height
+            s[72:74] = v_star[i]; s[74] = 0.0
+            k = int(code[i])
+            s[75:81] = 0.0 if k in (0, 2) else data["swing_twist"][i]      # left foot in contact -> zero twist
+            s[81:87] = 0.0 if k in (1, 2) else data["swing_twist"][i]
+            one = dict(J_left=data["J_left"][i:i + 1], J_right=data["J_right"][i:i + 1], J_neck=data["J_neck"][i:i + 1],
+                       J_com=data["J_com"][i:i + 1], q=q_des[i:i + 1], state=s[None, :])
+            try:
+                dq[i] = qs.ik_exact(ik_params, qs.ik_inputs_from_batch(one, 0), ik_form)["dq"]
+            except qs.QPOracleError:
+                ik_fail[i] += 1
+        q_des = q_des + 0.5 * p.dT * (dq + dq_prev); dq_prev = dq          # WalkingModule.cpp:741-744
+        # synthetic plant
+        w = np.stack([disturbance(p.seed, inst, t, 0), disturbance(p.seed, inst, t, 1)], 1)
+        com = com + p.dT * (-omega * (com - dcm))
+        dcm = c.a * dcm + c.b * u0 + p.noise * w
+        zmp_meas = u0.copy(); u_prev = u0.copy()
+        u0_log[t] = u0; dq_log[t] = dq
+    return dict(u0_log=u0_log, dq_log=dq_log, q_des=q_des, dcm=dcm, com=com, mpc_fail=mpc_fail, ik_fail=ik_fail)

@@ -1,0 +1,73 @@
+"""
+Device-resident tick pipeline (BASELINE configs 4/5; SURVEY §8f-1 tick harness, §8f-2 glue)
+against its CPU restatement oracle/tick_spec.py, which drives the exact solvers through the
+reference's per-tick call order (WalkingModule.cpp:578-745).
+"""
+import numpy as np
+import pytest
+
+
+def test_contact_schedule_and_reference_are_consistent(wca):
+    """CPU: the synthetic DCM reference satisfies xi_{t+1} = a xi_t + b zmp_t with the ZMP
+    reference inside the support polygon of the scheduled contact pair."""
+    from oracle import tick_spec as ts
+    p = ts.TickParams()
+    d = wca.synth.synth_tick_batch(6, 400)
+    a = np.exp(np.sqrt(p.gravity / p.com_height) * p.dT)
+    xi, z = d["ref_traj"], d["zmp_ref"]
+    assert np.abs(xi[:, 1:] - (a * xi[:, :-1] + (1 - a) * z[:, :-1])).max() < 1e-12
+    for t in range(0, 400, 7):
+        code = ts.contact_code(t, d["phase0"], p)
+        for i in range(6):
+            k = int(code[i]); nc = int(d["hull_tab_nc"][i, k])
+            assert (d["hull_tab_A"][i, k, :nc] @ z[i, t] <= d["hull_tab_b"][i, k, :nc] + 1e-12).all()
+    full = wca.synth.synth_tick_batch(6, 50)
+    part = wca.synth.synth_tick_batch(3, 50, first=3)
+    assert np.array_equal(part["ref_traj"], full["ref_traj"][3:]) and np.array_equal(part["phase0"], full["phase0"][3:])
+
+
+@pytest.mark.gpu
+def test_tick_pipeline_matches_cpu_restatement(wca, qs):
+    from oracle import tick_spec as ts
+    B, T = 24, 150            # > one contact change per instance (double support lasts 110 ticks)
+    p = ts.TickParams()
+    d = wca.synth.synth_tick_batch(B, T)
+    vmax = 0.45
+    ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax * np.ones(23)))
+    assert ref["mpc_fail"].sum() == 0 and ref["ik_fail"].sum() == 0
+    for use_graph in (False, True):
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax), log_ticks=T)
+        pipe.upload(d)
+        pipe.run(T, use_graph=use_graph)
+        out = pipe.download()
+        assert out["tick"] == T and out["mpc_fail"].sum() == 0 and out["ik_fail"].sum() == 0
+        # closed loop over 150 ticks: rounding differences are damped (|lambda| = 0.974), not amplified
+        assert np.abs(out["u0_log"] - ref["u0_log"]).max() <= 1e-9
+        assert np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8
+        assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9
+        assert np.abs(out["dcm"] - ref["dcm"]).max() <= 1e-9 and np.abs(out["com"] - ref["com"]).max() <= 1e-9
+        if not use_graph:
+            eager = out
+    assert np.array_equal(out["u0_log"], eager["u0_log"]) and np.array_equal(out["dq_log"], eager["dq_log"])   # graph == eager, bitwise
+    assert np.abs(ref["dq_log"]).max() == pytest.approx(vmax, abs=1e-12)        # velocity limits really bind
+
+
+@pytest.mark.gpu
+def test_tick_pipeline_long_run_is_stable_and_shard_invariant(wca):
+    """1000 ticks (config 5 length) on 512 robots: no solver failure, DCM stays on its reference,
+    and two half-batches reproduce the full batch bit for bit."""
+    B, T = 512, 1000
+    d = wca.synth.synth_tick_batch(B, T)
+
+    def run(data, first, count):
+        pipe = wca.TickPipeline(count, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.5), first=first)
+        pipe.upload(data)
+        pipe.run(T, use_graph=True)
+        return pipe.download()
+    full = run(d, 0, B)
+    assert full["tick"] == T and full["mpc_fail"].sum() == 0
+    assert full["ik_fail"].sum() <= 0.001 * B * T
+    assert np.abs(full["dcm"] - d["ref_traj"][:, T]).max() < 0.05
+    halves = [run(wca.synth.synth_tick_batch(B // 2, T, first=f), f, B // 2) for f in (0, B // 2)]
+    assert np.array_equal(np.concatenate([h["q_des"] for h in halves]), full["q_des"])
+    assert np.array_equal(np.concatenate([h["dcm"] for h in halves]), full["dcm"])

@@ -30,6 +30,7 @@ ABI_SYMBOLS = (
     "wcqp_mpc_create", "wcqp_mpc_destroy", "wcqp_mpc_get_condensed", "wcqp_mpc_get_matrices",
     "wcqp_mpc_solve_device", "wcqp_mpc_solve_host",
     "wcqp_ik_create", "wcqp_ik_destroy", "wcqp_ik_solve_device", "wcqp_ik_solve_host",
+    "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download",
 )
 
 
@@ -53,6 +54,23 @@ class IkParams(C.Structure):
                 ("k_pos_com", C.c_double), ("k_pos_foot", C.c_double),
                 ("k_att_foot", C.c_double), ("k_neck", C.c_double),
                 ("rho", C.c_double), ("tol", C.c_double)]
+
+
+class TickParams(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("first", C.c_int32), ("max_ticks", C.c_int32), ("log_ticks", C.c_int32),
+                ("step_ticks", C.c_int32), ("ds_ticks", C.c_int32),
+                ("k_com", C.c_double), ("k_zmp", C.c_double), ("noise", C.c_double), ("seed", C.c_uint64),
+                ("mpc", MpcParams), ("ik", IkParams)]
+
+
+class TickInputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("ref_traj", "hull_tab_A", "hull_tab_b", "hull_tab_nc", "phase0",
+                                          "J_left", "J_right", "J_neck", "J_com", "state0", "swing_twist",
+                                          "q0", "dcm0", "com0", "u_init")]
+
+
+class TickOutputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("u0_log", "dq_log", "q_des", "dcm", "com", "mpc_fail", "ik_fail", "tick")]
 
 
 _lib: Optional[C.CDLL] = None
@@ -80,6 +98,11 @@ def lib() -> C.CDLL:
         ik_args = [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp, dp, ip, up, up, dp, ip]
         L.wcqp_ik_solve_device.argtypes = ik_args + [vp]
         L.wcqp_ik_solve_host.argtypes = ik_args
+        L.wcqp_tick_create.argtypes = [C.POINTER(TickParams), C.POINTER(C.c_void_p)]
+        L.wcqp_tick_destroy.argtypes = [C.c_void_p]
+        L.wcqp_tick_upload.argtypes = [C.c_void_p, C.POINTER(TickInputs)]
+        L.wcqp_tick_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.wcqp_tick_download.argtypes = [C.c_void_p, C.POINTER(TickOutputs)]
         _lib = L
     return _lib
 
@@ -215,6 +238,52 @@ class IkSolver:
                                          active_lower or None, active_upper or None, foot_err or None,
                                          iters or None, stream or None),
               "wcqp_ik_solve_device")
+
+
+class TickPipeline:
+    """Handle over wcqp_tick_* — the device-resident MPC -> glue -> IK tick (configs 4/5)."""
+
+    def __init__(self, batch, max_ticks, mpc: MpcSolver, ik: IkSolver, first=0, log_ticks=0,
+                 step_ticks=180, ds_ticks=110, k_com=9.0, k_zmp=3.0, noise=1e-4, seed=99):
+        self.batch, self.max_ticks, self.log_ticks, self.dof = batch, max_ticks, log_ticks, ik.dof
+        self.params = TickParams(batch, first, max_ticks, log_ticks, step_ticks, ds_ticks, k_com, k_zmp, noise, seed,
+                                 mpc.params, ik.params)
+        self._h = C.c_void_p()
+        check(lib().wcqp_tick_create(C.byref(self.params), C.byref(self._h)), "wcqp_tick_create")
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            lib().wcqp_tick_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, data: dict):
+        f64 = ("ref_traj", "hull_tab_A", "hull_tab_b", "J_left", "J_right", "J_neck", "J_com", "state0",
+               "swing_twist", "q0", "dcm0", "com0", "u_init")
+        keep = {k: _f64(data[k]) for k in f64}
+        keep["hull_tab_nc"] = np.ascontiguousarray(data["hull_tab_nc"], dtype=np.int32)
+        keep["phase0"] = np.ascontiguousarray(data["phase0"], dtype=np.int32)
+        assert keep["ref_traj"].shape == (self.batch, self.max_ticks + self.params.mpc.horizon + 1, 2), keep["ref_traj"].shape
+        ins = TickInputs(**{k: keep[k].ctypes.data for k, _ in TickInputs._fields_})
+        check(lib().wcqp_tick_upload(self._h, C.byref(ins)), "wcqp_tick_upload")
+
+    def run(self, n_ticks: int, use_graph: bool = True, stream: int = 0):
+        check(lib().wcqp_tick_run(self._h, int(n_ticks), int(bool(use_graph)), stream or None), "wcqp_tick_run")
+
+    def download(self):
+        B, L, D = self.batch, self.log_ticks, self.dof
+        o = dict(u0_log=np.zeros((L, B, 2)), dq_log=np.zeros((L, B, D)), q_des=np.zeros((B, D)), dcm=np.zeros((B, 2)),
+                 com=np.zeros((B, 2)), mpc_fail=np.zeros(B, np.int64), ik_fail=np.zeros(B, np.int64), tick=np.zeros(1, np.int32))
+        outs = TickOutputs(**{k: o[k].ctypes.data for k, _ in TickOutputs._fields_})
+        check(lib().wcqp_tick_download(self._h, C.byref(outs)), "wcqp_tick_download")
+        o["tick"] = int(o["tick"][0])
+        return o
 
 
 def device_count() -> int:

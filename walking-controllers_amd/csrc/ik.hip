@@ -576,6 +576,10 @@ int ensure_device(wcqp_ik_s* h) {
 
 }  // namespace
 
+namespace wcqp {
+int ik_prepare(wcqp_ik_t h) { return h ? ensure_device(h) : WCQP_E_INVALID; }
+}  // namespace wcqp
+
 extern "C" {
 
 int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out) {

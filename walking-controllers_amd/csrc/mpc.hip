@@ -42,6 +42,7 @@ struct MpcDeviceConsts {
 __global__ __launch_bounds__(kBlock)
 void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
                           const double* __restrict__ x0, const double* __restrict__ ref, int ref_len,
+                          int ref_stride, const int* __restrict__ ref_start,
                           const double* __restrict__ u_prev,
                           const double* __restrict__ hull_A, const double* __restrict__ hull_b,
                           const int* __restrict__ hull_nc,
@@ -58,7 +59,9 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
     const long inst = live ? inst_raw : (long)batch - 1;   // dead slots shadow the last instance, never store
 
     // ---- u0_unc = sum_i Gr_i r_i + Gx x0 + Gu u_prev ---------------------------------
-    const double2* rp = reinterpret_cast<const double2*>(ref) + inst * ref_len;
+    // the reference window of an instance starts `*ref_start` stages into its trajectory (the
+    // deque of the reference advanced by that many ticks); instances are `ref_stride` stages apart
+    const double2* rp = reinterpret_cast<const double2*>(ref) + inst * ref_stride + (ref_start ? *ref_start : 0);
     const double2* gp = reinterpret_cast<const double2*>(c.Gr);
     double ux = 0.0, uy = 0.0;
     for (int i = t; i <= c.N; i += kLanesPerInstance) {
@@ -291,6 +294,39 @@ int ensure_device(wcqp_mpc_s* h) {
 
 }  // namespace
 
+namespace wcqp {
+
+int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, int ref_len, int ref_stride,
+                const int* ref_start_dev, const double* u_prev,
+                const double* hull_A, const double* hull_b, const int* hull_nc,
+                double* u0, int* status, unsigned* active, double* margin, hipStream_t stream) {
+    if (!h || batch < 0 || ref_len < 1 || ref_stride < ref_len) return WCQP_E_INVALID;
+    if (!x0 || !ref || !u_prev || !hull_A || !hull_b || !hull_nc || !u0 || !status) return WCQP_E_INVALID;
+    if (batch == 0) return WCQP_OK;
+    const int rc = ensure_device(h);
+    if (rc != WCQP_OK) return rc;
+    MpcDeviceConsts c;
+    c.Gr = h->d_Gr;
+    std::memcpy(c.Gx, h->Gx, sizeof(c.Gx));
+    std::memcpy(c.Gu, h->Gu, sizeof(c.Gu));
+    std::memcpy(c.S0, h->S0, sizeof(c.S0));
+    c.feas_tol = h->p.feas_tol;
+    c.hull_tol = h->p.convex_hull_tolerance;
+    c.N = h->N;
+    const unsigned grid = (unsigned)((batch + kInstPerWave - 1) / kInstPerWave);
+    hipLaunchKernelGGL(mpc_condensed_kernel, dim3(grid), dim3(kBlock), 0, stream,
+                       c, batch, x0, ref, ref_len, ref_stride, ref_start_dev, u_prev, hull_A, hull_b, hull_nc,
+                       u0, status, active, margin);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+int mpc_prepare(wcqp_mpc_t h) { return h ? ensure_device(h) : WCQP_E_INVALID; }
+int mpc_horizon(wcqp_mpc_t h) { return h ? h->N : 0; }
+void mpc_dynamics(wcqp_mpc_t h, double* a, double* b) { *a = h->a; *b = h->b; }
+
+}  // namespace wcqp
+
 extern "C" {
 
 int wcqp_mpc_create(const wcqp_mpc_params* params, wcqp_mpc_t* out) {
@@ -341,25 +377,8 @@ int wcqp_mpc_solve_device(wcqp_mpc_t h, int32_t batch,
                           const double* x0, const double* ref, int32_t ref_len, const double* u_prev,
                           const double* hull_A, const double* hull_b, const int32_t* hull_nc,
                           double* u0, int32_t* status, uint32_t* active, double* margin, void* stream) {
-    if (!h || batch < 0 || ref_len < 1) return WCQP_E_INVALID;
-    if (!x0 || !ref || !u_prev || !hull_A || !hull_b || !hull_nc || !u0 || !status) return WCQP_E_INVALID;
-    if (batch == 0) return WCQP_OK;
-    const int rc = ensure_device(h);
-    if (rc != WCQP_OK) return rc;
-    MpcDeviceConsts c;
-    c.Gr = h->d_Gr;
-    std::memcpy(c.Gx, h->Gx, sizeof(c.Gx));
-    std::memcpy(c.Gu, h->Gu, sizeof(c.Gu));
-    std::memcpy(c.S0, h->S0, sizeof(c.S0));
-    c.feas_tol = h->p.feas_tol;
-    c.hull_tol = h->p.convex_hull_tolerance;
-    c.N = h->N;
-    const unsigned grid = (unsigned)((batch + kInstPerWave - 1) / kInstPerWave);
-    hipLaunchKernelGGL(mpc_condensed_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
-                       c, batch, x0, ref, ref_len, u_prev, hull_A, hull_b, hull_nc,
-                       u0, status, active, margin);
-    WCQP_HIP_TRY(hipGetLastError());
-    return WCQP_OK;
+    return wcqp::mpc_enqueue(h, batch, x0, ref, ref_len, ref_len, nullptr, u_prev, hull_A, hull_b, hull_nc,
+                             u0, status, active, margin, (hipStream_t)stream);
 }
 
 int wcqp_mpc_solve_host(wcqp_mpc_t h, int32_t batch,

@@ -1,0 +1,309 @@
+// Device-resident tick pipeline (BASELINE configs 4/5, SURVEY.md §8f-1 tick harness and
+// §8f-2 MPC->IK glue).  See include/wcqp.h for the contract and oracle/tick_spec.py for the
+// CPU restatement every number is checked against.
+//
+// Reference call order reproduced (citations relative to /root/reference/modules/Walking_module):
+//   src/WalkingModule.cpp:578-597   StableDCMModel::integrateModel        -> tick_pre_kernel
+//   src/WalkingModule.cpp:604-636   MPC bracket                           -> mpc_condensed_kernel
+//   src/WalkingModule.cpp:657-695   WalkingZMPController + desired CoM    -> tick_glue_kernel
+//   src/WalkingModule.cpp:709-740   IK bracket                            -> ik_kernel
+//   src/WalkingModule.cpp:741-744   velocity integration                  -> tick_post_kernel
+//   src/WalkingModule.cpp:816       advanceReferenceSignals               -> tick counter in HBM
+#include <cstring>
+#include <new>
+#include <vector>
+#include "wcqp_internal.h"
+
+namespace {
+
+constexpr int kDof = 23;
+constexpr int kStateLen = WCQP_IK_STATE_LEN;
+
+struct TickDev {
+    // per-instance constants
+    const double* ref_traj; const double* hull_tab_A; const double* hull_tab_b; const int* hull_tab_nc;
+    const int* phase0; const double* swing_twist;
+    // per-instance state
+    double *dcm, *com, *zmp_meas, *u_prev, *u0, *c_ref, *v_ref, *p_star, *v_star_prev, *v_ref_prev;
+    double *q_des, *dq_prev, *dq, *hull_A, *hull_b, *state;
+    int *hull_nc, *code_prev, *mpc_status, *ik_status;
+    long long *mpc_fail, *ik_fail;
+    int* tick;
+    double *u0_log, *dq_log;
+    // scalars
+    int batch, first, traj_len, log_ticks, step_ticks, ds_ticks;
+    double omega, a, b, dT, k_com, k_zmp, noise, com_height;
+    unsigned long long seed;
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+// uniform in [-1, 1): identical integer arithmetic to oracle/tick_spec.py::disturbance
+__device__ __forceinline__ double disturbance(unsigned long long seed, unsigned long long inst, int tick, int axis) {
+    const unsigned long long base = mix64(inst * 0x9E3779B97F4A7C15ull + seed);
+    const unsigned long long h = mix64(base + ((unsigned long long)(2 * tick + axis) + 1ull) * 0x94D049BB133111EBull);
+    return (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+__device__ __forceinline__ int contact_code(int t, int phase0, int step_ticks, int ds_ticks) {
+    const int cyc = (t + phase0) % (2 * step_ticks);
+    const int s = cyc % step_ticks, side = cyc / step_ticks;
+    return s < ds_ticks ? 2 : side;                 // 0 = left only, 1 = right only, 2 = both
+}
+
+__global__ void tick_pre_kernel(TickDev d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.batch) return;
+    const int t = *d.tick;
+    const int code = contact_code(t, d.phase0[i], d.step_ticks, d.ds_ticks);
+    if (code != d.code_prev[i]) {
+        // WalkingController::setConvexHullConstraint: rows change only when the contact pair does
+        // (…PredictiveController.cpp:369-374); the reference then builds a new MPCSolver (cold start)
+        for (int k = 0; k < WCQP_HULL_ROWS; ++k) {
+            d.hull_A[(size_t)i * 16 + 2 * k] = d.hull_tab_A[((size_t)i * 3 + code) * 16 + 2 * k];
+            d.hull_A[(size_t)i * 16 + 2 * k + 1] = d.hull_tab_A[((size_t)i * 3 + code) * 16 + 2 * k + 1];
+            d.hull_b[(size_t)i * 8 + k] = d.hull_tab_b[((size_t)i * 3 + code) * 8 + k];
+        }
+        d.hull_nc[i] = d.hull_tab_nc[(size_t)i * 3 + code];
+        d.code_prev[i] = code;
+    }
+    // StableDCMModel::integrateModel (StableDCMModel.cpp:63-90), Tustin integrator
+    for (int ax = 0; ax < 2; ++ax) {
+        const double r = d.ref_traj[((size_t)i * d.traj_len + t) * 2 + ax];
+        const double v = -d.omega * (d.c_ref[2 * i + ax] - r);
+        d.c_ref[2 * i + ax] += 0.5 * d.dT * (v + d.v_ref_prev[2 * i + ax]);
+        d.v_ref_prev[2 * i + ax] = v;
+        d.v_ref[2 * i + ax] = v;
+    }
+}
+
+__global__ void tick_glue_kernel(TickDev d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.batch) return;
+    const int t = *d.tick;
+    const int code = d.code_prev[i];
+    const int st = d.mpc_status[i];
+    const bool ok = st == WCQP_STATUS_SOLVED || st == WCQP_STATUS_OUTSIDE_HULL;
+    if (!ok) d.mpc_fail[i] += 1;
+    double* s = d.state + (size_t)i * kStateLen;
+    for (int ax = 0; ax < 2; ++ax) {
+        const double u = ok ? d.u0[2 * i + ax] : d.u_prev[2 * i + ax];     // hold the last command on failure
+        // WalkingZMPController::evaluateControl (WalkingZMPController.cpp:146-173)
+        const double v = d.k_com * (d.c_ref[2 * i + ax] - d.com[2 * i + ax]) - d.k_zmp * (u - d.zmp_meas[2 * i + ax]) + d.v_ref[2 * i + ax];
+        d.p_star[2 * i + ax] += 0.5 * d.dT * (v + d.v_star_prev[2 * i + ax]);
+        d.v_star_prev[2 * i + ax] = v;
+        // desired CoM for the IK (WalkingModule.cpp:686-695)
+        s[66 + ax] = d.com[2 * i + ax];
+        s[69 + ax] = d.p_star[2 * i + ax];
+        s[72 + ax] = v;
+        // synthetic plant: LIPM with a bounded disturbance
+        const double xi = d.dcm[2 * i + ax];
+        d.com[2 * i + ax] += d.dT * (-d.omega * (d.com[2 * i + ax] - xi));
+        d.dcm[2 * i + ax] = d.a * xi + d.b * u + d.noise * disturbance(d.seed, (unsigned long long)(d.first + i), t, ax);
+        d.zmp_meas[2 * i + ax] = u;
+        d.u_prev[2 * i + ax] = u;
+        if (t < d.log_ticks) d.u0_log[((size_t)t * d.batch + i) * 2 + ax] = u;
+    }
+    s[68] = d.com_height; s[71] = d.com_height; s[74] = 0.0;
+    for (int k = 0; k < 6; ++k) {
+        const double tw = d.swing_twist[(size_t)i * 6 + k];
+        s[75 + k] = (code == 0 || code == 2) ? 0.0 : tw;      // a foot in contact keeps a zero twist
+        s[81 + k] = (code == 1 || code == 2) ? 0.0 : tw;
+    }
+}
+
+__global__ void tick_post_kernel(TickDev d) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.batch * kDof) return;
+    const int i = g / kDof;
+    const int t = *d.tick;
+    const bool ok = d.ik_status[i] == WCQP_STATUS_SOLVED;
+    const double v = ok ? d.dq[g] : 0.0;
+    if (!ok && g % kDof == 0) d.ik_fail[i] += 1;
+    d.q_des[g] += 0.5 * d.dT * (v + d.dq_prev[g]);             // WalkingModule.cpp:741-744
+    d.dq_prev[g] = v;
+    if (t < d.log_ticks) d.dq_log[(size_t)t * d.batch * kDof + g] = v;
+}
+
+__global__ void tick_advance_kernel(int* tick) { *tick += 1; }   // advanceReferenceSignals (WalkingModule.cpp:816)
+
+}  // namespace
+
+struct wcqp_tick_s {
+    wcqp_tick_params p{};
+    wcqp_mpc_t mpc = nullptr;
+    wcqp_ik_t ik = nullptr;
+    TickDev d{};
+    std::vector<void*> allocs;
+    double *J_left = nullptr, *J_right = nullptr, *J_neck = nullptr, *J_com = nullptr;
+    unsigned* mpc_active = nullptr; double* mpc_margin = nullptr;
+    unsigned *ik_lo = nullptr, *ik_up = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;
+    bool uploaded = false;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(wcqp_tick_s* h, T** out, size_t count) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return WCQP_E_NOMEM;
+    if (hipMemset(p, 0, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return WCQP_E_HIP;
+    h->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return WCQP_OK;
+}
+
+int enqueue_tick(wcqp_tick_s* h, hipStream_t s) {
+    const TickDev& d = h->d;
+    const int B = d.batch;
+    const int N = wcqp::mpc_horizon(h->mpc);
+    hipLaunchKernelGGL(tick_pre_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d);
+    int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick, d.u_prev,
+                               d.hull_A, d.hull_b, d.hull_nc, d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
+    if (rc != WCQP_OK) return rc;
+    hipLaunchKernelGGL(tick_glue_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d);
+    rc = wcqp_ik_solve_device(h->ik, B, h->J_left, h->J_right, h->J_neck, h->J_com, d.q_des, d.state,
+                              d.dq, d.ik_status, h->ik_lo, h->ik_up, nullptr, nullptr, s);
+    if (rc != WCQP_OK) return rc;
+    hipLaunchKernelGGL(tick_post_kernel, dim3((B * kDof + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(tick_advance_kernel, dim3(1), dim3(1), 0, s, d.tick);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
+    if (!params || !out || params->batch < 1 || params->max_ticks < 1) return WCQP_E_INVALID;
+    if (params->step_ticks < 2 || params->ds_ticks < 0 || params->ds_ticks > params->step_ticks) return WCQP_E_INVALID;
+    if (params->ik.dof != kDof) return WCQP_E_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        std::fprintf(stderr, "[wcqp] no HIP device: the tick pipeline has no CPU fallback\n");
+        return WCQP_E_HIP;
+    }
+    wcqp_tick_s* h = new (std::nothrow) wcqp_tick_s();
+    if (!h) return WCQP_E_NOMEM;
+    h->p = *params;
+    int rc = wcqp_mpc_create(&params->mpc, &h->mpc);
+    if (rc == WCQP_OK) rc = wcqp_ik_create(&params->ik, &h->ik);
+    if (rc == WCQP_OK) rc = wcqp::mpc_prepare(h->mpc);
+    if (rc == WCQP_OK) rc = wcqp::ik_prepare(h->ik);
+    if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
+    const size_t B = (size_t)params->batch;
+    const int N = params->mpc.horizon;
+    TickDev& d = h->d;
+    d.batch = params->batch; d.first = params->first; d.traj_len = params->max_ticks + N + 1;
+    d.log_ticks = params->log_ticks > 0 ? params->log_ticks : 0;
+    d.step_ticks = params->step_ticks; d.ds_ticks = params->ds_ticks;
+    d.dT = params->mpc.sampling_time; d.k_com = params->k_com; d.k_zmp = params->k_zmp;
+    d.noise = params->noise; d.seed = params->seed; d.com_height = params->mpc.com_height;
+    d.omega = std::sqrt(params->mpc.gravity / params->mpc.com_height);
+    wcqp::mpc_dynamics(h->mpc, &d.a, &d.b);
+    double *ref = nullptr, *hA = nullptr, *hb = nullptr, *sw = nullptr;
+    int *hn = nullptr, *ph = nullptr;
+    rc = WCQP_OK;
+#define A_(ptr, n) if (rc == WCQP_OK) rc = dev_alloc(h, &(ptr), (n))
+    A_(ref, B * d.traj_len * 2); A_(hA, B * 3 * 16); A_(hb, B * 3 * 8); A_(hn, B * 3); A_(ph, B); A_(sw, B * 6);
+    A_(d.dcm, B * 2); A_(d.com, B * 2); A_(d.zmp_meas, B * 2); A_(d.u_prev, B * 2); A_(d.u0, B * 2);
+    A_(d.c_ref, B * 2); A_(d.v_ref, B * 2); A_(d.v_ref_prev, B * 2); A_(d.p_star, B * 2); A_(d.v_star_prev, B * 2);
+    A_(d.q_des, B * kDof); A_(d.dq_prev, B * kDof); A_(d.dq, B * kDof);
+    A_(d.hull_A, B * 16); A_(d.hull_b, B * 8); A_(d.hull_nc, B); A_(d.code_prev, B);
+    A_(d.state, B * kStateLen); A_(d.mpc_status, B); A_(d.ik_status, B); A_(d.mpc_fail, B); A_(d.ik_fail, B);
+    A_(d.tick, 1); A_(d.u0_log, (size_t)d.log_ticks * B * 2); A_(d.dq_log, (size_t)d.log_ticks * B * kDof);
+    A_(h->J_left, B * 6 * 29); A_(h->J_right, B * 6 * 29); A_(h->J_neck, B * 3 * 29); A_(h->J_com, B * 3 * 29);
+    A_(h->mpc_active, B); A_(h->mpc_margin, B); A_(h->ik_lo, B); A_(h->ik_up, B);
+#undef A_
+    if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
+    d.ref_traj = ref; d.hull_tab_A = hA; d.hull_tab_b = hb; d.hull_tab_nc = hn; d.phase0 = ph; d.swing_twist = sw;
+    *out = h;
+    return WCQP_OK;
+}
+
+int wcqp_tick_destroy(wcqp_tick_t h) {
+    if (!h) return WCQP_E_INVALID;
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->mpc) wcqp_mpc_destroy(h->mpc);
+    if (h->ik) wcqp_ik_destroy(h->ik);
+    delete h;
+    return WCQP_OK;
+}
+
+int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
+    if (!h || !in) return WCQP_E_INVALID;
+    if (!in->ref_traj || !in->hull_tab_A || !in->hull_tab_b || !in->hull_tab_nc || !in->phase0 || !in->J_left ||
+        !in->J_right || !in->J_neck || !in->J_com || !in->state0 || !in->swing_twist || !in->q0 || !in->dcm0 ||
+        !in->com0 || !in->u_init) return WCQP_E_INVALID;
+    TickDev& d = h->d;
+    const size_t B = (size_t)d.batch;
+    WCQP_HIP_TRY(hipDeviceSynchronize());
+#define UP_(dst, src, n) WCQP_HIP_TRY(hipMemcpy((void*)(dst), (src), (n), hipMemcpyHostToDevice))
+    UP_(d.ref_traj, in->ref_traj, B * d.traj_len * 16); UP_(d.hull_tab_A, in->hull_tab_A, B * 3 * 128);
+    UP_(d.hull_tab_b, in->hull_tab_b, B * 3 * 64); UP_(d.hull_tab_nc, in->hull_tab_nc, B * 3 * 4);
+    UP_(d.phase0, in->phase0, B * 4); UP_(d.swing_twist, in->swing_twist, B * 48);
+    UP_(h->J_left, in->J_left, B * 6 * 29 * 8); UP_(h->J_right, in->J_right, B * 6 * 29 * 8);
+    UP_(h->J_neck, in->J_neck, B * 3 * 29 * 8); UP_(h->J_com, in->J_com, B * 3 * 29 * 8);
+    UP_(d.state, in->state0, B * kStateLen * 8); UP_(d.q_des, in->q0, B * kDof * 8);
+    UP_(d.dcm, in->dcm0, B * 16); UP_(d.com, in->com0, B * 16); UP_(d.c_ref, in->com0, B * 16); UP_(d.p_star, in->com0, B * 16);
+    UP_(d.zmp_meas, in->u_init, B * 16); UP_(d.u_prev, in->u_init, B * 16);
+#undef UP_
+    WCQP_HIP_TRY(hipMemset(d.v_ref_prev, 0, B * 16)); WCQP_HIP_TRY(hipMemset(d.v_star_prev, 0, B * 16));
+    WCQP_HIP_TRY(hipMemset(d.dq_prev, 0, B * kDof * 8)); WCQP_HIP_TRY(hipMemset(d.tick, 0, 4));
+    WCQP_HIP_TRY(hipMemset(d.code_prev, 0xFF, B * 4));           // -1: the first tick always loads its hull
+    WCQP_HIP_TRY(hipMemset(d.mpc_fail, 0, B * 8)); WCQP_HIP_TRY(hipMemset(d.ik_fail, 0, B * 8));
+    h->uploaded = true;
+    return WCQP_OK;
+}
+
+int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream) {
+    if (!h || n_ticks < 0 || !h->uploaded) return WCQP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_graph) {
+        for (int k = 0; k < n_ticks; ++k) { const int rc = enqueue_tick(h, s); if (rc != WCQP_OK) return rc; }
+        return WCQP_OK;
+    }
+    if (!h->graph_exec) {
+        // one tick = six launches, captured once; the tick index lives in HBM so the graph is tick-invariant
+        hipStream_t cs = nullptr;
+        WCQP_HIP_TRY(hipStreamCreate(&cs));
+        // a first plain tick would advance the state, so make sure lazy device state of the solver
+        // handles exists before capture (capture forbids allocations)
+        WCQP_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_tick(h, cs);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(cs, &g);
+        (void)hipStreamDestroy(cs);
+        if (rc != WCQP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) return WCQP_E_HIP;
+        h->graph = g;
+        WCQP_HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    }
+    for (int k = 0; k < n_ticks; ++k) WCQP_HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+    return WCQP_OK;
+}
+
+int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
+    if (!h || !out) return WCQP_E_INVALID;
+    const TickDev& d = h->d;
+    const size_t B = (size_t)d.batch;
+    WCQP_HIP_TRY(hipDeviceSynchronize());
+#define DN_(dst, src, n) if (dst) WCQP_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
+    DN_(out->u0_log, d.u0_log, (size_t)d.log_ticks * B * 16); DN_(out->dq_log, d.dq_log, (size_t)d.log_ticks * B * kDof * 8);
+    DN_(out->q_des, d.q_des, B * kDof * 8); DN_(out->dcm, d.dcm, B * 16); DN_(out->com, d.com, B * 16);
+    DN_(out->mpc_fail, d.mpc_fail, B * 8); DN_(out->ik_fail, d.ik_fail, B * 8); DN_(out->tick, d.tick, 4);
+#undef DN_
+    return WCQP_OK;
+}
+
+}  // extern "C"

@@ -258,3 +258,62 @@ def synth_ik_batch(count: int, seed: int = 4321, dof: int = 23, first: int = 0,
     return dict(J_left=np.ascontiguousarray(J_left), J_right=np.ascontiguousarray(J_right),
                 J_neck=np.ascontiguousarray(J_neck6[:, 3:6, :]), J_com=np.ascontiguousarray(J_com),
                 q=np.ascontiguousarray(q), state=state)
+
+
+# --------------------------------------------------------------------------------------
+def synth_tick_batch(count: int, n_ticks: int, seed: int = 2718, horizon: int = 50, first: int = 0,
+                     step_ticks: int = 180, ds_ticks: int = 110, dT: float = 0.01, com_height: float = 0.53,
+                     gravity: float = 9.81):
+    """Inputs of the device-resident tick pipeline (BASELINE configs 4/5): per instance a long
+    DCM reference trajectory (the deque the reference consumes one stage per tick), the
+    support-polygon rows of the three contact pairs (left, right, both), a random phase
+    offset of the step cycle, constant Jacobians/poses for the IK, initial states.
+
+    The DCM reference is dynamically consistent, the way the reference's planner builds it
+    (WM/src/TrajectoryGenerator.cpp:152-154): a ZMP reference that sits on the stance foot
+    (+ leftZMPDelta / rightZMPDelta, plannerParams.ini:39-40) in single support and moves
+    linearly to the next stance foot in double support, integrated BACKWARDS through
+    xi_t = (xi_{t+1} - b zmp_t) / a."""
+    rng = CounterRNG(seed ^ 0x5EED, first, count)
+    T = n_ticks + horizon + 1
+    yaw = rng.uniform(2, -0.2, 0.2)
+    dxy = np.concatenate([rng.uniform(1, -0.05, 0.05), rng.uniform(1, -0.01, 0.01)], 1)
+    phase0 = (rng.uniform(1)[:, 0] * (2 * step_ticks)).astype(np.int32)
+    dcm_n = rng.normal(2, 0.002)
+    swing = rng.normal(6, 0.2)
+    left_xy = np.zeros((count, 2)); left_xy[:, 1] = 0.5 * NOMINAL_WIDTH
+    right_xy = dxy.copy(); right_xy[:, 1] -= 0.5 * NOMINAL_WIDTH
+    hull_tab_A = np.zeros((count, 3, HULL_ROWS, 2)); hull_tab_b = np.zeros((count, 3, HULL_ROWS))
+    hull_tab_nc = np.zeros((count, 3), np.int32)
+    for i in range(count):
+        L = foot_corners(left_xy[i], yaw[i, 0]); R = foot_corners(right_xy[i], yaw[i, 1])
+        for k, pts in enumerate((L, R, np.vstack([L, R]))):
+            A, b, nc = hull_rows(pts)
+            hull_tab_A[i, k], hull_tab_b[i, k], hull_tab_nc[i, k] = A, b, nc
+
+    def rot2(a, v):
+        return np.stack([np.cos(a) * v[0] - np.sin(a) * v[1], np.sin(a) * v[0] + np.cos(a) * v[1]], -1)
+    zl = left_xy + rot2(yaw[:, 0], (0.03, -0.005))            # leftZMPDelta
+    zr = right_xy + rot2(yaw[:, 1], (0.03, 0.005))            # rightZMPDelta
+    Tz = T + 4 * step_ticks                                   # tail so that the backward pass has settled
+    tau = np.arange(Tz)[None, :]
+    cyc = (tau + phase0[:, None]) % (2 * step_ticks)
+    sidx = cyc % step_ticks
+    side = cyc // step_ticks                                  # 0: left is the stance foot of this step
+    cur = np.where(side[..., None] == 0, zl[:, None, :], zr[:, None, :])
+    prev = np.where(side[..., None] == 0, zr[:, None, :], zl[:, None, :])
+    lam = np.clip(sidx / float(ds_ticks), 0.0, 1.0)[..., None]
+    zmp = prev + lam * (cur - prev)
+    a = np.exp(np.sqrt(gravity / com_height) * dT); b = 1.0 - a
+    xi = np.zeros((count, Tz, 2))
+    xi[:, -1] = zmp[:, -1]
+    for t in range(Tz - 2, -1, -1):
+        xi[:, t] = (xi[:, t + 1] - b * zmp[:, t]) / a
+    ref = np.ascontiguousarray(xi[:, :T])
+    ik = synth_ik_batch(count, seed=seed + 1, first=first)
+    dcm0 = ref[:, 0, :] + dcm_n
+    return dict(first=first, ref_traj=ref, zmp_ref=np.ascontiguousarray(zmp[:, :T]), hull_tab_A=hull_tab_A,
+                hull_tab_b=hull_tab_b, hull_tab_nc=hull_tab_nc, phase0=phase0, J_left=ik["J_left"],
+                J_right=ik["J_right"], J_neck=ik["J_neck"], J_com=ik["J_com"], state0=ik["state"],
+                swing_twist=np.ascontiguousarray(swing), q0=ik["q"], dcm0=np.ascontiguousarray(dcm0),
+                com0=np.ascontiguousarray(dcm0.copy()), u_init=np.ascontiguousarray(zmp[:, 0].copy()))
