@@ -128,6 +128,9 @@ int wcqp_mpc_solve_host(wcqp_mpc_t h, int32_t batch,
  *          WM/src/WalkingQPInverseKinematics_qpOASES.cpp:284-362).
  * ===================================================================================== */
 #define WCQP_IK_FORM_QPOASES 0   /* bounds enforced, kappa = 1, feet always corrected        */
+#define WCQP_IK_ALG_DEFAULT   0
+#define WCQP_IK_ALG_SWEEP     1
+#define WCQP_IK_ALG_NULLSPACE 2
 #define WCQP_IK_FORM_OSQP    1   /* joint-limit rows are zero rows (never bind), extra
                                     k_attFoot on the neck gradient term, zero-twist rule
                                                                */
@@ -147,6 +150,8 @@ typedef struct wcqp_ik_params {
     double  k_pos_com, k_pos_foot, k_att_foot, k_neck;
     double  rho;                         /* weight of the A'A term that regularises H; 0 -> 1  */
     double  tol;                         /* bound-violation tolerance; 0 -> 1e-12              */
+    int32_t algorithm;                   /* 0 -> default (null-space kernel), 1 = sweep on H + rho A'A
+                                            (csrc/ik.hip), 2 = null-space (csrc/ik2.hip); same optimum  */
 } wcqp_ik_params;
 
 typedef struct wcqp_ik_s* wcqp_ik_t;

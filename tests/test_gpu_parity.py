@@ -116,17 +116,19 @@ def test_mpc_properties_at_full_size(wca):
 
 
 # -------------------------------------------------------------------------------- IK ---
-def _ik_solver(wca, form, vmax):
-    return wca.IkSolver(form=wca.IK_FORM_QPOASES if form == "qpoases" else wca.IK_FORM_OSQP, v_max=vmax)
+def _ik_solver(wca, form, vmax, algorithm=0):
+    return wca.IkSolver(form=wca.IK_FORM_QPOASES if form == "qpoases" else wca.IK_FORM_OSQP, v_max=vmax,
+                        algorithm=algorithm)
 
 
+@pytest.mark.parametrize("algorithm", [2, 1], ids=["nullspace", "sweep"])
 @pytest.mark.parametrize("name", ["ik_qpoases_v050_b1024.npz", "ik_qpoases_v030_b512.npz", "ik_osqp_b512.npz"])
-def test_ik_matches_golden(wca, golden_dir, name):
+def test_ik_matches_golden(wca, golden_dir, name, algorithm):
     g = _load(golden_dir, name)
     B, seed, form, vmax = int(g["count"]), int(g["seed"]), str(g["form"]), float(g["v_max"])
     b = wca.synth.synth_ik_batch(B, seed=seed)
     assert np.array_equal(b["J_left"][:2], g["in_J_left"]) and np.array_equal(b["state"][:2], g["in_state"])
-    out = _ik_solver(wca, form, vmax).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    out = _ik_solver(wca, form, vmax, algorithm).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
     ok = g["status"] == 0
     assert (out["status"][ok] == wca.STATUS_SOLVED).all()
     assert (out["status"][~ok] != wca.STATUS_SOLVED).all()
@@ -138,12 +140,13 @@ def test_ik_matches_golden(wca, golden_dir, name):
     assert np.array_equal(out["active_upper"][cc], g["active_upper"][cc])
 
 
+@pytest.mark.parametrize("algorithm", [2, 1], ids=["nullspace", "sweep"])
 @pytest.mark.parametrize("form,vmax", [("qpoases", 0.4), ("qpoases", 0.22), ("osqp", 0.3)])
-def test_ik_against_oracle_live(wca, qs, form, vmax):
+def test_ik_against_oracle_live(wca, qs, form, vmax, algorithm):
     B = 160
     b = wca.synth.synth_ik_batch(B, seed=99)
     p = qs.IKParams(v_max=vmax * np.ones(23))
-    out = _ik_solver(wca, form, vmax).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    out = _ik_solver(wca, form, vmax, algorithm).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
     checked = 0
     for i in range(B):
         x = qs.ik_inputs_from_batch(b, i)
@@ -174,17 +177,34 @@ def test_ik_osqp_form_quirks(wca, qs):
     assert np.abs(a["dq"] - q["dq"]).max() > 1e-3
 
 
-def test_ik_com_as_cost_variant(wca, qs):
+@pytest.mark.parametrize("algorithm", [2, 1], ids=["nullspace", "sweep"])
+def test_ik_com_as_cost_variant(wca, qs, algorithm):
     """useCoMAsConstraint = 0: 12 equality rows, CoM task moves into the cost."""
     B = 48
     b = wca.synth.synth_ik_batch(B, seed=17)
     p = qs.IKParams(use_com_as_constraint=False, v_max=0.4 * np.ones(23))
-    s = wca.IkSolver(form=wca.IK_FORM_QPOASES, use_com_as_constraint=False, v_max=0.4)
+    s = wca.IkSolver(form=wca.IK_FORM_QPOASES, use_com_as_constraint=False, v_max=0.4, algorithm=algorithm)
     out = s.solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
     for i in range(B):
         r = qs.ik_exact(p, qs.ik_inputs_from_batch(b, i), "qpoases")
         assert out["status"][i] == wca.STATUS_SOLVED
         assert np.abs(out["dq"][i] - r["dq"]).max() <= SOL_TOL
+
+
+def test_ik_stance_foot_touches_only_the_base(wca, qs):
+    """iCub-shaped structure: the reference's floating base IS the stance-foot
+    link, so that foot's Jacobian has zero joint columns.  The column-pivoted elimination must
+    pick base columns for those rows."""
+    B = 64
+    b = wca.synth.synth_ik_batch(B, seed=23)
+    JL = b["J_left"].copy(); JL[:, :, 6:] = 0.0
+    p = qs.IKParams(v_max=5.0 * np.ones(23))
+    for alg in (2, 1):
+        out = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=5.0, algorithm=alg).solve_host(JL, b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+        for i in range(B):
+            x = qs.ik_inputs_from_batch(dict(b, J_left=JL), i)
+            r = qs.ik_exact(p, x, "qpoases")
+            assert out["status"][i] == 0 and np.abs(out["dq"][i] - r["dq"]).max() <= SOL_TOL
 
 
 def test_ik_properties_at_full_size(wca):

@@ -25,27 +25,16 @@
 #include <cstring>
 #include <limits>
 #include <new>
-#include "wcqp_internal.h"
+#include "ik_common.h"
 
 namespace {
 
-constexpr int kDof = 23;
-constexpr int kNV = kDof + 6;          // 29
+using namespace wcqp_ik;
+
 constexpr int kLD = 30;                // leading dim of 29-wide LDS rows: even (16-B aligned b128
                                        // broadcasts) and 60 dwords mod 64 -> at most 2-way on row-per-lane reads
 constexpr int kLDG = 18;               // leading dim of G+ rows (<= 16 columns)
 constexpr int kRows = 18;              // stacked task rows: J_left 6 | J_right 6 | J_com 3 | J_neck 3
-constexpr int kStateLen = WCQP_IK_STATE_LEN;
-
-struct IkDeviceParams {
-    double lam[32];        // Lambda diagonal per variable (0 on the base)       base.cpp:64-67
-    double kq[32];         // w_i * K_i per variable                              base.cpp:70-72,87-89
-    double qreg[32];       // regularisation posture per variable (rad)
-    double vlo[32], vhi[32];   // variable bounds; base = -/+ DBL_MAX            qp.cpp:39-49
-    double Wn[9], Wc[9];
-    double k_pos_com, k_pos_foot, k_att_foot, k_neck, kappa, rho, tol;
-    int form, max_iter;
-};
 
 template <bool USE_COM>
 struct IkLayout {
@@ -83,24 +72,6 @@ struct IkLayout {
     // two instances per workgroup, 8 workgroups per CU (2 waves per SIMD) must fit in 160 KiB
     static_assert(2 * PER_INST * 8 <= 20480, "LDS budget: 8 workgroups per CU");
 };
-
-// rotation error component k of unskew(0.5 (E - E')), E = R Rd'     Utils.cpp:22-27
-__device__ __forceinline__ double rot_err(const double* R, const double* Rd, int k) {
-    const int a = (k + 2) % 3, b = (k + 1) % 3;
-    const double eab = R[3 * a] * Rd[3 * b] + R[3 * a + 1] * Rd[3 * b + 1] + R[3 * a + 2] * Rd[3 * b + 2];
-    const double eba = R[3 * b] * Rd[3 * a] + R[3 * b + 1] * Rd[3 * a + 1] + R[3 * b + 2] * Rd[3 * a + 2];
-    return 0.5 * (eab - eba);
-}
-
-// Broadcast of lane `SRC` of each 32-lane group to every lane of that group: ds_swizzle in
-// bit-mask mode (and = 0, or = SRC, xor = 0) moves data through the LDS crossbar without
-// touching LDS memory, so no write -> read round trip is needed.
-template <int SRC>
-__device__ __forceinline__ double group_bcast(double v) {
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (SRC & 31) << 5);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (SRC & 31) << 5);
-    return __hiloint2double(hi, lo);
-}
 
 // Symmetric sweep over pivots 0..SZ-1 of the matrix whose row i sits in `row` of lane i.
 // On exit row = -(A^-1) row.  Lanes >= SZ must hold zero rows (they act as padding).
@@ -278,7 +249,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 Mr[j] = fma(own, c2.x, Mr[j]);
                 if (j + 1 < kNV) Mr[j + 1] = fma(own, c2.y, Mr[j + 1]);
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every row's LDS reads
+            wcqp::pin_result(Mr[0]);   // keep the scheduler from hoisting every row's LDS reads
         }
         const double lam_i = prm->lam[i];
 #pragma unroll
@@ -310,7 +281,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             if (j + 1 < kNV) acc = fma(Mr[j + 1], c2.y, acc);
         }
         Gr[c] = acc;
-        __builtin_amdgcn_sched_barrier(0);
+        wcqp::pin_result(Gr[c]);
     }
     if (var) {
 #pragma unroll
@@ -394,7 +365,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
             for (int d = 0; d < MEQ; ++d) acc = fma(Gr[d], Sv[d * L::LDS_S + c], acc);
             Er[c] = acc;
-            __builtin_amdgcn_sched_barrier(0);
+            wcqp::pin_result(Er[c]);
         }
         int nW = 0;
         const int max_iter = prm->max_iter;
@@ -586,6 +557,11 @@ int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out) {
     if (!params || !out) return WCQP_E_INVALID;
     if (params->dof != kDof) return WCQP_E_UNSUPPORTED;      // kernels are unrolled for iCub's 23 DoF
     if (params->form != WCQP_IK_FORM_QPOASES && params->form != WCQP_IK_FORM_OSQP) return WCQP_E_INVALID;
+    if (params->algorithm < 0 || params->algorithm > WCQP_IK_ALG_NULLSPACE) return WCQP_E_INVALID;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < r; ++c)          // the kernels use W J and J'W interchangeably: symmetric weights only
+            if (params->neck_weight[3 * r + c] != params->neck_weight[3 * c + r] ||
+                params->com_weight[3 * r + c] != params->com_weight[3 * c + r]) return WCQP_E_INVALID;
     wcqp_ik_s* h = new (std::nothrow) wcqp_ik_s();
     if (!h) return WCQP_E_NOMEM;
     h->p = *params;
@@ -635,6 +611,9 @@ int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
     if (batch == 0) return WCQP_OK;
     const int rc = ensure_device(h);
     if (rc != WCQP_OK) return rc;
+    if (h->p.algorithm != WCQP_IK_ALG_SWEEP)
+        return wcqp_ik::ik2_launch(h->d_prm, h->p.use_com_as_constraint != 0, batch, J_left, J_right, J_neck, J_com,
+                                   q, state, dq, status, active_lower, active_upper, foot_err, iters, (hipStream_t)stream);
     const unsigned grid = (unsigned)((batch + 1) / 2);
     if (h->p.use_com_as_constraint)
         hipLaunchKernelGGL(ik_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream,

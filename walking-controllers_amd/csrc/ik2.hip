@@ -1,0 +1,553 @@
+// Jacobian QP-IK, second kernel: NULL-SPACE formulation (32 lanes per instance, two per wave).
+//
+// Same QP, same inputs/outputs and same reference citations as ik.hip; different algebra,
+// chosen after profiling ik.hip (53 % of wave cycles parked on LDS round trips, 6 k
+// instructions and 256 VGPRs per instance pair):
+//
+//   1. Gauss-Jordan on [A | b] with column pivoting.  Lane j holds COLUMN j of A in registers
+//      (lane 29 holds b, so the right-hand side rides along for free).  After meq steps the
+//      basic variables are  x_B = b' - F x_N  and only nN = 29 - meq = 14 variables are free.
+//   2. Reduced Hessian  Hr = Z'HZ = D_N + F'D_B F + (N Z)'W(N Z)  (14 x 14, SPD whenever the
+//      KKT matrix is regular — H itself is only PSD) built row-per-lane over the free lanes,
+//      addressed through a compact index (prefix count of free lanes).
+//   3. Hr^-1 by the symmetric sweep (14 pivots instead of 29 + 15), x_N = -Hr^-1 g_r.
+//   4. Bounds: the same Goldfarb-Idnani dual active set as ik.hip, fed with full-space columns
+//      tau_p = Z Hr^-1 Z' e_p.
+// About 2.2 k instructions per instance pair instead of 6 k, and ~1/2 the registers.
+#include <cmath>
+#include <limits>
+#include "ik_common.h"
+
+namespace {
+
+using namespace wcqp_ik;
+
+constexpr int kLDF = 16;      // leading dim of a stored F column (meq <= 15 entries)
+
+template <bool USE_COM>
+struct Ik2Layout {
+    static constexpr int MEQ = USE_COM ? 15 : 12;       // equality rows
+    static constexpr int NCOST = USE_COM ? 3 : 6;       // cost rows: [J_com;] J_neck
+    static constexpr int NN = kNV - MEQ;                // free (non-basic) variables
+    static constexpr int NK = NN + 1;                   // compact slots: free variables + the rhs lane
+    static constexpr int KMAX = NN;
+    static constexpr int LDL = KMAX;
+    static constexpr int TCS = 30;
+    // persistent
+    static constexpr int OFF_FK = 0;                    // [NK][kLDF]   F columns by compact index (slot NN = b')
+    static constexpr int OFF_P = OFF_FK + NK * kLDF;
+    // phase A (set-up)
+    static constexpr int OFF_ST = OFF_P;                // [112] state + q
+    static constexpr int OFF_CB = OFF_ST + 112;         // [2][16] pivot column, double-buffered
+    static constexpr int OFF_RD = OFF_CB + 32;          // [16][8] per row r: {D, g, cost-row entries} of its basic variable
+    static constexpr int OFF_WNZ = OFF_RD + 16 * 8;     // [NK][NCOST + (NCOST & 1)]
+    static constexpr int LDW = NCOST + (NCOST & 1);
+    static constexpr int OFF_COL = OFF_WNZ + NK * LDW;  // [2][32] sweep columns, double-buffered
+    static constexpr int OFF_GR = OFF_COL + 64;         // [32] reduced gradient / x_N by compact index
+    static constexpr int END_A = OFF_GR + 32;
+    // phase B (active set) reuses the phase-A area
+    static constexpr int OFF_TC = OFF_P;                // [KMAX][TCS]
+    static constexpr int OFF_LK = OFF_TC + KMAX * TCS;  // [KMAX][LDL]
+    static constexpr int OFF_V0 = OFF_LK + KMAX * LDL;  // vbuf
+    static constexpr int OFF_V1 = OFF_V0 + 32;          // sign / z
+    static constexpr int OFF_V2 = OFF_V1 + 32;          // tp
+    static constexpr int OFF_V3 = OFF_V2 + 32;          // published Hinv row / t by compact index
+    static constexpr int OFF_R = OFF_V3 + 32;           // [20] dual step
+    static constexpr int OFF_MU = OFF_R + 20;
+    static constexpr int OFF_WS = OFF_MU + 20;
+    static constexpr int OFF_WI = OFF_WS + 20;
+    static constexpr int OFF_INFO = OFF_WI + 20;        // [4]
+    static constexpr int END_B = OFF_INFO + 4;
+    static constexpr int OFF_B = (END_A > END_B ? END_A : END_B);   // [16] task rhs (kept for foot errors)
+    static constexpr int PER_INST = ((OFF_B + 16) + 1) & ~1;
+};
+
+// xor-butterfly over the 32 lanes of a group (ds_swizzle bit-mask mode: and = 0x1f, xor = M)
+template <int M>
+__device__ __forceinline__ double group_xor(double v) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x1f | (M << 10));
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x1f | (M << 10));
+    return __hiloint2double(hi, lo);
+}
+
+template <bool USE_COM>
+__global__ __launch_bounds__(64, 3)
+void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
+                const double* __restrict__ JL, const double* __restrict__ JR,
+                const double* __restrict__ JN, const double* __restrict__ JC,
+                const double* __restrict__ qpos, const double* __restrict__ state,
+                double* __restrict__ dq_out, int* __restrict__ status_out,
+                unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
+                double* __restrict__ ferr_out, int* __restrict__ iters_out)
+{
+    using L = Ik2Layout<USE_COM>;
+    constexpr int MEQ = L::MEQ, NCOST = L::NCOST, NN = L::NN, NK = L::NK, KMAX = L::KMAX, LDW = L::LDW;
+    __shared__ __attribute__((aligned(16))) double smem[2][L::PER_INST];
+
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    const int i = lane & 31;                       // variable owned by this lane; lane 29 = rhs column
+    const long inst_raw = (long)blockIdx.x * 2 + half;
+    const bool live = inst_raw < batch;
+    const long inst = live ? inst_raw : (long)batch - 1;
+    double* S = smem[half];
+    double* Fk = S + L::OFF_FK;
+    double* st = S + L::OFF_ST;
+    double* bvec = S + L::OFF_B;
+    const double inf = std::numeric_limits<double>::infinity();
+    const bool var = i < kNV;
+    const bool rhs_lane = i == kNV;
+
+    // ---------------- phase 0: loads (column i of every task Jacobian) -------------------
+    double a[MEQ];          // column i of A = [J_left; J_right; (J_com)]; on lane 29: b
+    double cn[NCOST];       // column i of the cost rows [ (J_com;) J_neck ]
+    {
+        const double* jl = JL + inst * (6 * kNV);
+        const double* jr = JR + inst * (6 * kNV);
+        const double* jc = JC + inst * (3 * kNV);
+        const double* jn = JN + inst * (3 * kNV);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a[r] = var ? jl[r * kNV + i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a[6 + r] = var ? jr[r * kNV + i] : 0.0;
+        if constexpr (USE_COM) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) a[12 + r] = var ? jc[r * kNV + i] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cn[r] = var ? jn[r * kNV + i] : 0.0;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cn[r] = var ? jc[r * kNV + i] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cn[3 + r] = var ? jn[r * kNV + i] : 0.0;
+        }
+        const double* sp = state + inst * kStateLen;
+        st[i] = sp[i];
+        st[i + 32] = sp[i + 32];
+        if (i + 64 < kStateLen) st[i + 64] = sp[i + 64];
+        if (i < kDof) st[kStateLen + i] = qpos[inst * kDof + i];
+    }
+    wcqp::wave_lds_fence();
+
+    // ---------------- phase 1: task rhs b (lane r < MEQ) and gradient g ------------------
+    const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
+    double b_mine = 0.0;
+    if (i < MEQ) {
+        if (i < 12) {
+            const int foot = i / 6, k = i % 6;
+            const double* p  = st + (foot ? 12 : 0);
+            const double* R  = st + (foot ? 15 : 3);
+            const double* pd = st + (foot ? 36 : 24);
+            const double* Rd = st + (foot ? 39 : 27);
+            const double* tw = st + (foot ? 81 : 75);
+            const double corr = k < 3 ? prm->k_pos_foot * (p[k] - pd[k]) : prm->k_att_foot * rot_err(R, Rd, k - 3);
+            const bool skip = osqp_form && tw[0] == tw[1] && tw[0] == 0.0;        // osqp.cpp:286-306
+            b_mine = skip ? tw[k] : tw[k] - corr;
+        } else {
+            const int k = i - 12;
+            b_mine = st[72 + k] - prm->k_pos_com * (st[66 + k] - st[69 + k]);
+        }
+        bvec[i] = b_mine;
+    }
+    double g = 0.0;             // gradient entry of this variable (osqp.cpp:181-196, qp.cpp:161-178)
+    const double Di = prm->lam[i];
+    {
+        const double kap = prm->kappa * (-prm->k_neck);
+        const double e0 = kap * rot_err(st + 48, st + 57, 0);
+        const double e1 = kap * rot_err(st + 48, st + 57, 1);
+        const double e2 = kap * rot_err(st + 48, st + 57, 2);
+        const double y0 = prm->Wn[0] * e0 + prm->Wn[1] * e1 + prm->Wn[2] * e2;
+        const double y1 = prm->Wn[3] * e0 + prm->Wn[4] * e1 + prm->Wn[5] * e2;
+        const double y2 = prm->Wn[6] * e0 + prm->Wn[7] * e1 + prm->Wn[8] * e2;
+        constexpr int NO = NCOST - 3;                      // neck rows offset inside cn
+        if (var) {
+            g = -(cn[NO] * y0 + cn[NO + 1] * y1 + cn[NO + 2] * y2);
+            if (i >= 6) g -= prm->kq[i] * (prm->qreg[i] - st[kStateLen + i - 6]);
+            if constexpr (!USE_COM) {
+                const double w0 = prm->Wc[0] * st[72] + prm->Wc[1] * st[73] + prm->Wc[2] * st[74];
+                const double w1 = prm->Wc[3] * st[72] + prm->Wc[4] * st[73] + prm->Wc[5] * st[74];
+                const double w2 = prm->Wc[6] * st[72] + prm->Wc[7] * st[73] + prm->Wc[8] * st[74];
+                g -= cn[0] * w0 + cn[1] * w1 + cn[2] * w2;
+            }
+        }
+    }
+    wcqp::wave_lds_fence();
+    if (rhs_lane) {
+#pragma unroll
+        for (int r = 0; r < MEQ; ++r) a[r] = bvec[r];
+    }
+
+    // ---------------- phase 2: Gauss-Jordan with column pivoting --------------------------
+    bool basic = false;
+    int myrow = 0;
+    bool ok = true;
+    {
+        double* cbase = S + L::OFF_CB;
+#pragma unroll
+        for (int r = 0; r < MEQ; ++r) {
+            // arg-max of |a[r]| over the free variable lanes: the key keeps the magnitude's top
+            // 59 bits and carries 31 - lane in the low 5, so one v_max_f64 per butterfly step
+            // yields both the pivot lane and a deterministic (lowest-lane) tie-break
+            double key = 0.0;
+            if (var && !basic) {
+                const long long bits = (__double_as_longlong(fabs(a[r])) & ~31ll) | (long long)(31 - i);
+                key = __longlong_as_double(bits);
+            }
+            key = fmax(key, group_xor<16>(key));
+            key = fmax(key, group_xor<8>(key));
+            key = fmax(key, group_xor<4>(key));
+            key = fmax(key, group_xor<2>(key));
+            key = fmax(key, group_xor<1>(key));
+            const int pl = 31 - (int)(__double_as_longlong(key) & 31ll);
+            double* cb = cbase + 16 * (r & 1);
+            if (i == pl) {
+                basic = true; myrow = r;
+#pragma unroll
+                for (int q = 0; q < MEQ; ++q) cb[q] = a[q];
+            }
+            wcqp::wave_lds_fence();
+            const double piv = cb[r];
+            ok = ok && (fabs(piv) > 1e-12);
+            const double t = a[r] * wcqp::fast_rcp(piv);
+#pragma unroll
+            for (int q = 0; q < MEQ; q += 2) {
+                const double2 c2 = *reinterpret_cast<const double2*>(cb + q);
+                if (q != r) a[q] = fma(-c2.x, t, a[q]);
+                if (q + 1 < MEQ && q + 1 != r) a[q + 1] = fma(-c2.y, t, a[q + 1]);
+            }
+            a[r] = t;
+        }
+    }
+    // compact index of the free lanes (prefix count inside the 32-lane group); rhs lane -> slot NN
+    const bool free_var = var && !basic;
+    const unsigned long long fm = __ballot(free_var);
+    const unsigned gm = (unsigned)((fm >> (32 * half)) & 0xffffffffull);
+    const int kap_i = free_var ? __popc(gm & ((1u << i) - 1u)) : (rhs_lane ? NN : 31);
+    const bool rowlane = free_var || rhs_lane;          // lanes that own a row of [Hr | h_rhs]
+    ok = ok && (__popc(gm) == NN);
+
+    // ---------------- phase 3: reduced Hessian rows ---------------------------------------
+    double* rd = S + L::OFF_RD;
+    double* wnz = S + L::OFF_WNZ;
+    if (basic) {
+        rd[myrow * 8] = Di; rd[myrow * 8 + 1] = g;
+#pragma unroll
+        for (int s = 0; s < NCOST; ++s) rd[myrow * 8 + 2 + s] = cn[s];
+    }
+    if (rowlane) {
+#pragma unroll
+        for (int r = 0; r < MEQ; ++r) Fk[kap_i * kLDF + r] = a[r];
+    }
+    wcqp::wave_lds_fence();
+    // one pass over the rows: nz = column of N Z (rhs lane: -N x_p), g_r partial, a := F_j[r] D_B[r]
+    double nz[NCOST];
+#pragma unroll
+    for (int s = 0; s < NCOST; ++s) nz[s] = rhs_lane ? 0.0 : cn[s];
+    double gr = g;
+#pragma unroll
+    for (int r = 0; r < MEQ; ++r) {
+        const double2 dg = *reinterpret_cast<const double2*>(rd + r * 8);
+        const double ar = a[r];
+#pragma unroll
+        for (int s = 0; s < NCOST; s += 2) {
+            const double2 n2 = *reinterpret_cast<const double2*>(rd + r * 8 + 2 + s);
+            nz[s] = fma(-n2.x, ar, nz[s]);
+            if (s + 1 < NCOST) nz[s + 1] = fma(-n2.y, ar, nz[s + 1]);
+        }
+        gr = fma(-ar, dg.y, gr);
+        a[r] = ar * dg.x;       // F itself now lives in Fk
+        if ((r & 3) == 3) wcqp::pin_result(gr);
+    }
+    {
+        double w[NCOST];
+        if constexpr (USE_COM) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) w[s] = prm->Wn[3 * s] * nz[0] + prm->Wn[3 * s + 1] * nz[1] + prm->Wn[3 * s + 2] * nz[2];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                w[s] = prm->Wc[3 * s] * nz[0] + prm->Wc[3 * s + 1] * nz[1] + prm->Wc[3 * s + 2] * nz[2];
+                w[3 + s] = prm->Wn[3 * s] * nz[3] + prm->Wn[3 * s + 1] * nz[4] + prm->Wn[3 * s + 2] * nz[5];
+            }
+        }
+        if (rowlane) {
+#pragma unroll
+            for (int s = 0; s < NCOST; ++s) wnz[kap_i * LDW + s] = w[s];
+        }
+    }
+    wcqp::wave_lds_fence();
+    double Hr[NK];
+    const double fmask = free_var ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < MEQ; r += 2) {
+            const double2 f2 = *reinterpret_cast<const double2*>(Fk + k * kLDF + r);
+            acc = fma(a[r], f2.x, acc);
+            if (r + 1 < MEQ) acc = fma(a[r + 1], f2.y, acc);
+        }
+#pragma unroll
+        for (int s = 0; s < NCOST; s += 2) {
+            const double2 w2 = *reinterpret_cast<const double2*>(wnz + k * LDW + s);
+            acc = fma(nz[s], w2.x, acc);
+            if (s + 1 < NCOST) acc = fma(nz[s + 1], w2.y, acc);
+        }
+        // non-free lanes are zero padding; a multiply (not a select) keeps hipcc from turning the row
+        // into a branch and hoisting every LDS read of the loop in front of it (they then spill)
+        Hr[k] = fmask * (acc + (k == kap_i ? Di : 0.0));
+        wcqp::pin_result(Hr[k]);
+    }
+    gr -= Hr[NN];               // g_r = g_j - F_j' g_B - (b'-dependent column)
+
+    // ---------------- phase 4: Hr^-1 (sweep over the NN compact pivots), x_N, x_B ---------
+    {
+        double* col = S + L::OFF_COL;
+        col[kap_i] = Hr[0];
+        wcqp::wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < NN; ++k) {
+            double* cb = col + 32 * (k & 1);
+            double* nb = col + 32 * ((k + 1) & 1);
+            const double piv = cb[k];
+            ok = ok && (piv > 0.0);
+            const double d = wcqp::fast_rcp(piv);
+            const double ck = Hr[k];
+            const double f0 = ck * d;
+            const double f = (kap_i == k) ? (1.0 - d) : f0;
+            if (k + 1 < NN) {
+                Hr[k + 1] = fma(-f, cb[k + 1], Hr[k + 1]);
+                nb[kap_i] = Hr[k + 1];                       // publish the next column early
+            }
+#pragma unroll
+            for (int j = 0; j < NN; j += 2) {
+                const double2 c2 = *reinterpret_cast<const double2*>(cb + j);
+                if (j != k && j != k + 1) Hr[j] = fma(-f, c2.x, Hr[j]);
+                if (j + 1 < NN && j + 1 != k && j + 1 != k + 1) Hr[j + 1] = fma(-f, c2.y, Hr[j + 1]);
+            }
+            Hr[k] = (kap_i == k) ? -d : f0;
+            wcqp::wave_lds_fence();
+        }
+    }
+    // Hr now holds -(Hr^-1) rows on the free lanes
+    double* grv = S + L::OFF_GR;
+    if (rowlane) grv[kap_i] = gr;
+    wcqp::wave_lds_fence();
+    double xn = 0.0;
+#pragma unroll
+    for (int k = 0; k < NN; ++k) xn = fma(Hr[k], grv[k], xn);   // x_N = -Hinv g_r
+    wcqp::wave_lds_fence();
+    if (free_var) grv[kap_i] = xn;
+    wcqp::wave_lds_fence();
+    double nu = free_var ? xn : 0.0;
+    if (basic) {
+        double acc = Fk[NN * kLDF + myrow];                      // b'
+#pragma unroll
+        for (int k = 0; k < NN; ++k) acc = fma(-Fk[k * kLDF + myrow], grv[k], acc);
+        nu = acc;
+    }
+    wcqp::wave_lds_fence();
+
+    // ---------------- phase 5: joint-velocity bounds (qpOASES form) ------------------------
+    int st_code = ok ? WCQP_STATUS_SOLVED : WCQP_STATUS_NUMERIC;
+    int it = 0;
+    bool in_w = false;
+    double my_sig = 0.0;
+    const double lo = var ? prm->vlo[i] : -inf, hi = var ? prm->vhi[i] : inf;
+    const double tol = prm->tol;
+    const bool need = !osqp_form && var && i >= 6 && fmax(nu - hi, lo - nu) > tol;
+    if (__ballot(need) != 0ull) {
+        double* Tc = S + L::OFF_TC;
+        double* Lk = S + L::OFF_LK;
+        double* vbuf = S + L::OFF_V0;
+        double* zbuf = S + L::OFF_V1;
+        double* tpb = S + L::OFF_V2;
+        double* tkb = S + L::OFF_V3;
+        double* rvec = S + L::OFF_R;
+        double* Wmu = S + L::OFF_MU;
+        double* Wsg = S + L::OFF_WS;
+        int* Wi = reinterpret_cast<int*>(S + L::OFF_WI);
+        int* info = reinterpret_cast<int*>(S + L::OFF_INFO);
+        int nW = 0;
+        const int max_iter = prm->max_iter;
+        bool running = st_code == WCQP_STATUS_SOLVED;
+        while (running) {
+            const double v_hi = nu - hi, v_lo = lo - nu;
+            vbuf[i] = (var && i >= 6 && !in_w) ? fmax(v_hi, v_lo) : -inf;
+            zbuf[i] = v_hi >= v_lo ? 1.0 : -1.0;
+            wcqp::wave_lds_fence();
+            double s = -inf;
+            int p = 6;
+#pragma unroll 1
+            for (int j = 6; j < kNV; ++j) {
+                const double vj = vbuf[j];
+                if (vj > s) { s = vj; p = j; }
+            }
+            if (!(s > tol)) break;
+            if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; break; }
+            ++it;
+            const double sig = zbuf[p];
+            wcqp::wave_lds_fence();
+            // t = Hr^-1 Z' e_p over the free lanes, then tau = Z t over all lanes
+            if (i == p) {
+                info[0] = basic ? 1 : 0;
+                info[1] = basic ? myrow : kap_i;
+                if (!basic) {
+#pragma unroll
+                    for (int k = 0; k < NN; ++k) tkb[k] = -Hr[k];          // row == column (symmetric)
+                }
+            }
+            wcqp::wave_lds_fence();
+            const bool p_basic = info[0] != 0;
+            const int p_idx = info[1];
+            double tfree = 0.0;
+            if (p_basic) {
+#pragma unroll
+                for (int k = 0; k < NN; ++k) tfree = fma(Hr[k], Fk[k * kLDF + p_idx], tfree);   // -Hinv F[row_p,:]'
+            } else if (free_var) {
+                tfree = tkb[kap_i];
+            }
+            wcqp::wave_lds_fence();
+            if (free_var) tkb[kap_i] = tfree;
+            wcqp::wave_lds_fence();
+            double tp = free_var ? tfree : 0.0;
+            if (basic) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NN; ++k) acc = fma(-Fk[k * kLDF + myrow], tkb[k], acc);
+                tp = acc;
+            }
+            tp *= sig;
+            double mu_p = 0.0;
+            tpb[i] = tp;
+            wcqp::wave_lds_fence();
+            const double ppp = sig * tpb[p];
+#pragma unroll 1
+            for (int inner = 0; inner <= KMAX + 1; ++inner) {
+#pragma unroll 1
+                for (int a2 = 0; a2 < nW; ++a2) {
+                    const int wa = Wi[a2];
+                    const double sa = Wsg[a2];
+#pragma unroll 1
+                    for (int bb = 0; bb <= a2; ++bb) {
+                        double sum = sa * Tc[bb * L::TCS + wa];
+#pragma unroll 1
+                        for (int c = 0; c < bb; ++c) sum -= Lk[a2 * L::LDL + c] * Lk[bb * L::LDL + c];
+                        if (a2 == bb) Lk[a2 * L::LDL + a2] = sqrt(fmax(sum, 1e-300));
+                        else Lk[a2 * L::LDL + bb] = sum / Lk[bb * L::LDL + bb];
+                    }
+                    double y = sa * tpb[wa];
+#pragma unroll 1
+                    for (int c = 0; c < a2; ++c) y -= Lk[a2 * L::LDL + c] * rvec[c];
+                    rvec[a2] = y / Lk[a2 * L::LDL + a2];
+                }
+#pragma unroll 1
+                for (int a2 = nW - 1; a2 >= 0; --a2) {
+                    double y = rvec[a2];
+#pragma unroll 1
+                    for (int c = a2 + 1; c < nW; ++c) y -= Lk[c * L::LDL + a2] * rvec[c];
+                    rvec[a2] = y / Lk[a2 * L::LDL + a2];
+                }
+                double z = tp;
+#pragma unroll 1
+                for (int a2 = 0; a2 < nW; ++a2) z = fma(-rvec[a2], Tc[a2 * L::TCS + (var ? i : 0)], z);
+                zbuf[i] = z;
+                wcqp::wave_lds_fence();
+                const double nzv = sig * zbuf[p];
+                const double t2 = (nW < KMAX && nzv > 1e-10 * ppp) ? s / nzv : inf;
+                double t1 = inf;
+                int jd = -1;
+#pragma unroll 1
+                for (int a2 = 0; a2 < nW; ++a2) {
+                    const double ra = rvec[a2];
+                    if (ra > 0.0) {
+                        const double tt = Wmu[a2] / ra;
+                        if (tt < t1) { t1 = tt; jd = a2; }
+                    }
+                }
+                const double t = fmin(t1, t2);
+                if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; running = false; break; }
+                nu = fma(-t, z, nu);
+#pragma unroll 1
+                for (int a2 = 0; a2 < nW; ++a2) Wmu[a2] = Wmu[a2] - t * rvec[a2];
+                mu_p += t;
+                s -= t * nzv;
+                if (t2 <= t1) {
+                    if (var) Tc[nW * L::TCS + i] = tp;
+                    Wi[nW] = p; Wsg[nW] = sig; Wmu[nW] = mu_p;
+                    if (i == p) { in_w = true; my_sig = sig; }
+                    ++nW;
+                    break;
+                }
+                if (i == Wi[jd]) { in_w = false; my_sig = 0.0; }
+#pragma unroll 1
+                for (int a2 = jd; a2 < nW - 1; ++a2) {
+                    if (var) Tc[a2 * L::TCS + i] = Tc[(a2 + 1) * L::TCS + i];
+                    const int w1 = Wi[a2 + 1]; const double s1 = Wsg[a2 + 1], m1 = Wmu[a2 + 1];
+                    Wi[a2] = w1; Wsg[a2] = s1; Wmu[a2] = m1;
+                }
+                --nW;
+                ++it;
+                wcqp::wave_lds_fence();
+            }
+            wcqp::wave_lds_fence();
+        }
+        {
+            const double dev = !(var && i >= 6) ? 0.0
+                             : (in_w ? fabs(nu - (my_sig > 0.0 ? hi : lo)) : fmax(nu - hi, lo - nu));
+            vbuf[i] = dev == dev ? dev : inf;
+            wcqp::wave_lds_fence();
+            double worst = 0.0;
+#pragma unroll 1
+            for (int j = 6; j < kNV; ++j) worst = fmax(worst, vbuf[j]);
+            if (st_code == WCQP_STATUS_SOLVED && worst > 1e-9) st_code = WCQP_STATUS_NUMERIC;
+            if (st_code == WCQP_STATUS_SOLVED && in_w) nu = my_sig > 0.0 ? hi : lo;
+        }
+    }
+
+    // ---------------- outputs ---------------------------------------------------------------
+    const unsigned long long bu = __ballot(in_w && my_sig > 0.0);
+    const unsigned long long bl = __ballot(in_w && my_sig < 0.0);
+    if (live) {
+        if (i >= 6 && var) dq_out[inst * kDof + (i - 6)] = nu;
+        if (i == 0) {
+            status_out[inst] = st_code;
+            if (aup_out) aup_out[inst] = (unsigned)((bu >> (32 * half)) & 0xffffffffull) >> 6;
+            if (alo_out) alo_out[inst] = (unsigned)((bl >> (32 * half)) & 0xffffffffull) >> 6;
+            if (iters_out) iters_out[inst] = it;
+        }
+    }
+    if (ferr_out) {
+        double* nub = S + L::OFF_FK;                 // F is dead now
+        wcqp::wave_lds_fence();
+        nub[i] = var ? nu : 0.0;
+        wcqp::wave_lds_fence();
+        if (i < 12 && live) {
+            const double* jrow = (i < 6 ? JL + inst * (6 * kNV) + i * kNV : JR + inst * (6 * kNV) + (i - 6) * kNV);
+            double acc = b_mine;
+            for (int k = 0; k < kNV; ++k) acc = fma(-jrow[k], nub[k], acc);
+            ferr_out[inst * 12 + i] = acc;           // b - J nu (osqp.cpp:430-454, qp.cpp:364-401)
+        }
+    }
+}
+
+}  // namespace
+
+namespace wcqp_ik {
+
+int ik2_launch(const IkDeviceParams* d_prm, bool use_com, int batch,
+               const double* JL, const double* JR, const double* JN, const double* JC,
+               const double* q, const double* state, double* dq, int* status,
+               unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
+    const unsigned grid = (unsigned)((batch + 1) / 2);
+    if (use_com)
+        hipLaunchKernelGGL(ik2_kernel<true>, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+                           dq, status, alo, aup, ferr, iters);
+    else
+        hipLaunchKernelGGL(ik2_kernel<false>, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+                           dq, status, alo, aup, ferr, iters);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+}  // namespace wcqp_ik

@@ -51,6 +51,14 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// In a fully unrolled loop of "broadcast LDS reads -> FMA chain -> one result" hipcc (ROCm 7.2)
+// issues every iteration's reads up front and sinks the FMA chains to the first use of the
+// results, so hundreds of loaded values are live at once and get spilled to scratch
+// (sched_barrier does not help: the IR is already reordered).  Passing each iteration's result
+// through an empty volatile asm with a memory clobber pins both: the reads cannot cross it and
+// the chain has to finish in front of it.
+__device__ __forceinline__ void pin_result(double& x) { __asm__ volatile("" : "+v"(x) :: "memory"); }
+
 // 1/x: v_rcp_f64 seed + two Newton steps (error <= ~1 ulp; the QPs need 1e-9, not
 // correctly-rounded division, and the IEEE division sequence is ~3x longer).
 __device__ __forceinline__ double fast_rcp(double x) {
