@@ -42,7 +42,6 @@ struct IkLayout {
     static constexpr int NC1 = MEQ + 1;                 // columns of G+ = [A' g~]
     static constexpr int KMAX = kNV - MEQ;              // most bounds that can be active at once
     static constexpr int LDS_S = MEQ + (MEQ & 1);       // leading dim of Sinv rows
-    static constexpr int LDL = KMAX;
     static constexpr int TCS = 30;                      // stride of one stored column of P (29 live lanes)
     // ---- per-instance LDS map (doubles) ----
     static constexpr int OFF_CR = 0;                    // [18][kLD]   phases 1-5
@@ -51,13 +50,13 @@ struct IkLayout {
     // phase 6 reuses the matrix area
     static constexpr int OFF_TC = 0;                    // [KMAX][TCS]
     static constexpr int OFF_SV = OFF_TC + KMAX * TCS;  // [MEQ][LDS_S]
-    static constexpr int OFF_LK = OFF_SV + MEQ * LDS_S; // [KMAX][LDL]
-    static constexpr int OFF_GROW = OFF_LK + KMAX * LDL; // [16] one row of G
-    static constexpr int OFF_R = OFF_GROW + 16;         // [20] dual step r
-    static constexpr int OFF_MU = OFF_R + 20;           // [20] multipliers of W
-    static constexpr int OFF_WS = OFF_MU + 20;          // [20] signs of W
-    static constexpr int OFF_WI = OFF_WS + 20;          // [20] ints (stored in doubles' space)
-    static constexpr int END_AS = OFF_WI + 20;
+    static constexpr int LDR = KMAX | 1;
+    static constexpr int OFF_RINV = OFF_SV + MEQ * LDS_S;   // [KMAX][LDR]
+    static constexpr int OFF_GROW = OFF_RINV + KMAX * LDR + ((KMAX * LDR) & 1); // [16] one row of G
+    static constexpr int OFF_R = OFF_GROW + 16;         // [32] dual step per slot
+    static constexpr int OFF_C = OFF_R + 32;            // [32]
+    static constexpr int OFF_WI = OFF_C + 32;           // [32] ints
+    static constexpr int END_AS = OFF_WI + 16;
     static_assert(END_AS <= END_MAT, "active-set scratch must fit in the dead matrix area");
     static constexpr int OFF_ST = END_MAT;              // [112] state 87 + q 23; later 4 x [32] vectors
     static constexpr int OFF_V0 = OFF_ST;               // vbuf   (violations)
@@ -340,18 +339,11 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const double tol = prm->tol;
     const bool need = !osqp_form && var && i >= 6 && fmax(nu - hi, lo - nu) > tol;
     if (__ballot(need) != 0ull) {
-        double* Tc = S + L::OFF_TC;
         double* Sv = S + L::OFF_SV;
-        double* Lk = S + L::OFF_LK;
-        double* vbuf = S + L::OFF_V0;
-        double* zbuf = S + L::OFF_V1;
-        double* tpb = S + L::OFF_V2;
         double* rowbuf = S + L::OFF_V3;
         double* grow = S + L::OFF_GROW;
-        double* rvec = S + L::OFF_R;
-        double* Wmu = S + L::OFF_MU;
-        double* Wsg = S + L::OFF_WS;
-        int* Wi = reinterpret_cast<int*>(S + L::OFF_WI);
+        const GiScratch w{S + L::OFF_TC, S + L::OFF_RINV, S + L::OFF_V0, S + L::OFF_V1, S + L::OFF_V2,
+                          S + L::OFF_R, S + L::OFF_C, reinterpret_cast<int*>(S + L::OFF_WI)};
         // E = G Sinv (row i in registers): publish Sinv rows once
         if (i < MEQ) {
 #pragma unroll
@@ -367,28 +359,8 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             Er[c] = acc;
             wcqp::pin_result(Er[c]);
         }
-        int nW = 0;
-        const int max_iter = prm->max_iter;
-        bool running = st_code == WCQP_STATUS_SOLVED;
-        while (running) {
-            // most violated bound outside W
-            const double v_hi = nu - hi, v_lo = lo - nu;
-            vbuf[i] = (var && i >= 6 && !in_w) ? fmax(v_hi, v_lo) : -inf;
-            zbuf[i] = v_hi >= v_lo ? 1.0 : -1.0;
-            wcqp::wave_lds_fence();
-            double s = -inf;
-            int p = 6;
-#pragma unroll 1
-            for (int j = 6; j < kNV; ++j) {
-                const double vj = vbuf[j];
-                if (vj > s) { s = vj; p = j; }
-            }
-            if (!(s > tol)) break;
-            if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; break; }
-            ++it;
-            const double sig = zbuf[p];
-            wcqp::wave_lds_fence();
-            // tp = sig * P[:, p],  P = Minv - E G'
+        // tau_p = sig * P[:, p],  P = Minv - E G'
+        auto column_of_P = [&](int p, double sig) -> double {
             if (i == p) {
 #pragma unroll
                 for (int j = 0; j < kNV; ++j) rowbuf[j] = Mr[j];
@@ -399,99 +371,11 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             double tp = var ? rowbuf[i] : 0.0;
 #pragma unroll
             for (int c = 0; c < MEQ; ++c) tp = fma(-Er[c], grow[c], tp);
-            tp *= sig;
-            double mu_p = 0.0;
-            tpb[i] = tp;
             wcqp::wave_lds_fence();
-            const double ppp = sig * tpb[p];             // P[p][p] > 0
-#pragma unroll 1
-            for (int inner = 0; inner <= KMAX + 1; ++inner) {
-                // dual step r = R^-1 c,  R_ab = sig_a Tc[b][w_a],  c_a = sig_a tp[w_a]
-#pragma unroll 1
-                for (int a = 0; a < nW; ++a) {
-                    const int wa = Wi[a];
-                    const double sa = Wsg[a];
-#pragma unroll 1
-                    for (int bb = 0; bb <= a; ++bb) {
-                        double sum = sa * Tc[bb * L::TCS + wa];
-#pragma unroll 1
-                        for (int c = 0; c < bb; ++c) sum -= Lk[a * L::LDL + c] * Lk[bb * L::LDL + c];
-                        if (a == bb) Lk[a * L::LDL + a] = sqrt(fmax(sum, 1e-300));
-                        else Lk[a * L::LDL + bb] = sum / Lk[bb * L::LDL + bb];
-                    }
-                    double y = sa * tpb[wa];
-#pragma unroll 1
-                    for (int c = 0; c < a; ++c) y -= Lk[a * L::LDL + c] * rvec[c];
-                    rvec[a] = y / Lk[a * L::LDL + a];
-                }
-#pragma unroll 1
-                for (int a = nW - 1; a >= 0; --a) {
-                    double y = rvec[a];
-#pragma unroll 1
-                    for (int c = a + 1; c < nW; ++c) y -= Lk[c * L::LDL + a] * rvec[c];
-                    rvec[a] = y / Lk[a * L::LDL + a];
-                }
-                // primal step z = tp - sum_a r_a Tc[a]
-                double z = tp;
-#pragma unroll 1
-                for (int a = 0; a < nW; ++a) z = fma(-rvec[a], Tc[a * L::TCS + (var ? i : 0)], z);
-                zbuf[i] = z;
-                wcqp::wave_lds_fence();
-                const double nz = sig * zbuf[p];
-                // a full active set (nW == n - meq) leaves no direction: p is then dependent by
-                // construction; otherwise dependence shows as a vanishing Schur complement
-                const double t2 = (nW < KMAX && nz > 1e-10 * ppp) ? s / nz : inf;
-                double t1 = inf;
-                int jd = -1;
-#pragma unroll 1
-                for (int a = 0; a < nW; ++a) {
-                    const double ra = rvec[a];
-                    if (ra > 0.0) {
-                        const double tt = Wmu[a] / ra;
-                        if (tt < t1) { t1 = tt; jd = a; }
-                    }
-                }
-                const double t = fmin(t1, t2);
-                if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; running = false; break; }
-                nu = fma(-t, z, nu);
-#pragma unroll 1
-                for (int a = 0; a < nW; ++a) Wmu[a] = Wmu[a] - t * rvec[a];
-                mu_p += t;
-                s -= t * nz;
-                if (t2 <= t1) {                          // full step: p joins W
-                    if (var) Tc[nW * L::TCS + i] = tp;
-                    Wi[nW] = p; Wsg[nW] = sig; Wmu[nW] = mu_p;
-                    if (i == p) { in_w = true; my_sig = sig; }
-                    ++nW;
-                    break;
-                }
-                // partial step: constraint jd leaves W
-                if (i == Wi[jd]) { in_w = false; my_sig = 0.0; }
-#pragma unroll 1
-                for (int a = jd; a < nW - 1; ++a) {
-                    if (var) Tc[a * L::TCS + i] = Tc[(a + 1) * L::TCS + i];
-                    const int w1 = Wi[a + 1]; const double s1 = Wsg[a + 1], m1 = Wmu[a + 1];
-                    Wi[a] = w1; Wsg[a] = s1; Wmu[a] = m1;
-                }
-                --nW;
-                ++it;
-                wcqp::wave_lds_fence();
-            }
-            wcqp::wave_lds_fence();
-        }
-        // certificate: every bound holds and every active bound is tight, else the walk
-        // lost accuracy (near-dependent working set) and the answer must not read SOLVED
-        {
-            const double dev = !(var && i >= 6) ? 0.0
-                             : (in_w ? fabs(nu - (my_sig > 0.0 ? hi : lo)) : fmax(nu - hi, lo - nu));
-            vbuf[i] = dev == dev ? dev : inf;
-            wcqp::wave_lds_fence();
-            double worst = 0.0;
-#pragma unroll 1
-            for (int j = 6; j < kNV; ++j) worst = fmax(worst, vbuf[j]);
-            if (st_code == WCQP_STATUS_SOLVED && worst > 1e-9) st_code = WCQP_STATUS_NUMERIC;
-            if (st_code == WCQP_STATUS_SOLVED && in_w) nu = my_sig > 0.0 ? hi : lo;
-        }
+            return tp * sig;
+        };
+        gi_active_set<KMAX, L::TCS, L::LDR>(w, i, half, var, lo, hi, tol, prm->max_iter, nu, st_code, it, in_w, my_sig,
+                                            column_of_P);
     }
 
     // ---------------- outputs ------------------------------------------------------------

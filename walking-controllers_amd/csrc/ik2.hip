@@ -31,7 +31,6 @@ struct Ik2Layout {
     static constexpr int NN = kNV - MEQ;                // free (non-basic) variables
     static constexpr int NK = NN + 1;                   // compact slots: free variables + the rhs lane
     static constexpr int KMAX = NN;
-    static constexpr int LDL = KMAX;
     static constexpr int TCS = 30;
     // persistent
     static constexpr int OFF_FK = 0;                    // [NK][kLDF]   F columns by compact index (slot NN = b')
@@ -47,28 +46,20 @@ struct Ik2Layout {
     static constexpr int END_A = OFF_GR + 32;
     // phase B (active set) reuses the phase-A area
     static constexpr int OFF_TC = OFF_P;                // [KMAX][TCS]
-    static constexpr int OFF_LK = OFF_TC + KMAX * TCS;  // [KMAX][LDL]
-    static constexpr int OFF_V0 = OFF_LK + KMAX * LDL;  // vbuf
+    static constexpr int LDR = KMAX | 1;                // odd leading dim: row-per-lane accesses spread over banks
+    static constexpr int OFF_RINV = OFF_TC + KMAX * TCS;// [KMAX][LDR]
+    static constexpr int OFF_V0 = OFF_RINV + KMAX * LDR + ((KMAX * LDR) & 1);
     static constexpr int OFF_V1 = OFF_V0 + 32;          // sign / z
     static constexpr int OFF_V2 = OFF_V1 + 32;          // tp
     static constexpr int OFF_V3 = OFF_V2 + 32;          // published Hinv row / t by compact index
-    static constexpr int OFF_R = OFF_V3 + 32;           // [20] dual step
-    static constexpr int OFF_MU = OFF_R + 20;
-    static constexpr int OFF_WS = OFF_MU + 20;
-    static constexpr int OFF_WI = OFF_WS + 20;
-    static constexpr int OFF_INFO = OFF_WI + 20;        // [4]
+    static constexpr int OFF_R = OFF_V3 + 32;           // [32] dual step per slot
+    static constexpr int OFF_C = OFF_R + 32;            // [32]
+    static constexpr int OFF_WI = OFF_C + 32;           // [32] ints
+    static constexpr int OFF_INFO = OFF_WI + 16;        // [4]
     static constexpr int END_B = OFF_INFO + 4;
     static constexpr int OFF_B = (END_A > END_B ? END_A : END_B);   // [16] task rhs (kept for foot errors)
     static constexpr int PER_INST = ((OFF_B + 16) + 1) & ~1;
 };
-
-// xor-butterfly over the 32 lanes of a group (ds_swizzle bit-mask mode: and = 0x1f, xor = M)
-template <int M>
-__device__ __forceinline__ double group_xor(double v) {
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x1f | (M << 10));
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x1f | (M << 10));
-    return __hiloint2double(hi, lo);
-}
 
 template <bool USE_COM>
 __global__ __launch_bounds__(64, 3)
@@ -82,6 +73,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 {
     using L = Ik2Layout<USE_COM>;
     constexpr int MEQ = L::MEQ, NCOST = L::NCOST, NN = L::NN, NK = L::NK, KMAX = L::KMAX, LDW = L::LDW;
+    (void)NK;
     __shared__ __attribute__((aligned(16))) double smem[2][L::PER_INST];
 
     const int lane = threadIdx.x;
@@ -357,38 +349,12 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const double tol = prm->tol;
     const bool need = !osqp_form && var && i >= 6 && fmax(nu - hi, lo - nu) > tol;
     if (__ballot(need) != 0ull) {
-        double* Tc = S + L::OFF_TC;
-        double* Lk = S + L::OFF_LK;
-        double* vbuf = S + L::OFF_V0;
-        double* zbuf = S + L::OFF_V1;
-        double* tpb = S + L::OFF_V2;
+        const GiScratch w{S + L::OFF_TC, S + L::OFF_RINV, S + L::OFF_V0, S + L::OFF_V1, S + L::OFF_V2,
+                          S + L::OFF_R, S + L::OFF_C, reinterpret_cast<int*>(S + L::OFF_WI)};
         double* tkb = S + L::OFF_V3;
-        double* rvec = S + L::OFF_R;
-        double* Wmu = S + L::OFF_MU;
-        double* Wsg = S + L::OFF_WS;
-        int* Wi = reinterpret_cast<int*>(S + L::OFF_WI);
         int* info = reinterpret_cast<int*>(S + L::OFF_INFO);
-        int nW = 0;
-        const int max_iter = prm->max_iter;
-        bool running = st_code == WCQP_STATUS_SOLVED;
-        while (running) {
-            const double v_hi = nu - hi, v_lo = lo - nu;
-            vbuf[i] = (var && i >= 6 && !in_w) ? fmax(v_hi, v_lo) : -inf;
-            zbuf[i] = v_hi >= v_lo ? 1.0 : -1.0;
-            wcqp::wave_lds_fence();
-            double s = -inf;
-            int p = 6;
-#pragma unroll 1
-            for (int j = 6; j < kNV; ++j) {
-                const double vj = vbuf[j];
-                if (vj > s) { s = vj; p = j; }
-            }
-            if (!(s > tol)) break;
-            if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; break; }
-            ++it;
-            const double sig = zbuf[p];
-            wcqp::wave_lds_fence();
-            // t = Hr^-1 Z' e_p over the free lanes, then tau = Z t over all lanes
+        // tau_p = Z Hr^-1 Z' e_p: t over the free lanes first, then the basic lanes through F
+        auto column_of_P = [&](int p, double sig) -> double {
             if (i == p) {
                 info[0] = basic ? 1 : 0;
                 info[1] = basic ? myrow : kap_i;
@@ -417,92 +383,11 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 for (int k = 0; k < NN; ++k) acc = fma(-Fk[k * kLDF + myrow], tkb[k], acc);
                 tp = acc;
             }
-            tp *= sig;
-            double mu_p = 0.0;
-            tpb[i] = tp;
             wcqp::wave_lds_fence();
-            const double ppp = sig * tpb[p];
-#pragma unroll 1
-            for (int inner = 0; inner <= KMAX + 1; ++inner) {
-#pragma unroll 1
-                for (int a2 = 0; a2 < nW; ++a2) {
-                    const int wa = Wi[a2];
-                    const double sa = Wsg[a2];
-#pragma unroll 1
-                    for (int bb = 0; bb <= a2; ++bb) {
-                        double sum = sa * Tc[bb * L::TCS + wa];
-#pragma unroll 1
-                        for (int c = 0; c < bb; ++c) sum -= Lk[a2 * L::LDL + c] * Lk[bb * L::LDL + c];
-                        if (a2 == bb) Lk[a2 * L::LDL + a2] = sqrt(fmax(sum, 1e-300));
-                        else Lk[a2 * L::LDL + bb] = sum / Lk[bb * L::LDL + bb];
-                    }
-                    double y = sa * tpb[wa];
-#pragma unroll 1
-                    for (int c = 0; c < a2; ++c) y -= Lk[a2 * L::LDL + c] * rvec[c];
-                    rvec[a2] = y / Lk[a2 * L::LDL + a2];
-                }
-#pragma unroll 1
-                for (int a2 = nW - 1; a2 >= 0; --a2) {
-                    double y = rvec[a2];
-#pragma unroll 1
-                    for (int c = a2 + 1; c < nW; ++c) y -= Lk[c * L::LDL + a2] * rvec[c];
-                    rvec[a2] = y / Lk[a2 * L::LDL + a2];
-                }
-                double z = tp;
-#pragma unroll 1
-                for (int a2 = 0; a2 < nW; ++a2) z = fma(-rvec[a2], Tc[a2 * L::TCS + (var ? i : 0)], z);
-                zbuf[i] = z;
-                wcqp::wave_lds_fence();
-                const double nzv = sig * zbuf[p];
-                const double t2 = (nW < KMAX && nzv > 1e-10 * ppp) ? s / nzv : inf;
-                double t1 = inf;
-                int jd = -1;
-#pragma unroll 1
-                for (int a2 = 0; a2 < nW; ++a2) {
-                    const double ra = rvec[a2];
-                    if (ra > 0.0) {
-                        const double tt = Wmu[a2] / ra;
-                        if (tt < t1) { t1 = tt; jd = a2; }
-                    }
-                }
-                const double t = fmin(t1, t2);
-                if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; running = false; break; }
-                nu = fma(-t, z, nu);
-#pragma unroll 1
-                for (int a2 = 0; a2 < nW; ++a2) Wmu[a2] = Wmu[a2] - t * rvec[a2];
-                mu_p += t;
-                s -= t * nzv;
-                if (t2 <= t1) {
-                    if (var) Tc[nW * L::TCS + i] = tp;
-                    Wi[nW] = p; Wsg[nW] = sig; Wmu[nW] = mu_p;
-                    if (i == p) { in_w = true; my_sig = sig; }
-                    ++nW;
-                    break;
-                }
-                if (i == Wi[jd]) { in_w = false; my_sig = 0.0; }
-#pragma unroll 1
-                for (int a2 = jd; a2 < nW - 1; ++a2) {
-                    if (var) Tc[a2 * L::TCS + i] = Tc[(a2 + 1) * L::TCS + i];
-                    const int w1 = Wi[a2 + 1]; const double s1 = Wsg[a2 + 1], m1 = Wmu[a2 + 1];
-                    Wi[a2] = w1; Wsg[a2] = s1; Wmu[a2] = m1;
-                }
-                --nW;
-                ++it;
-                wcqp::wave_lds_fence();
-            }
-            wcqp::wave_lds_fence();
-        }
-        {
-            const double dev = !(var && i >= 6) ? 0.0
-                             : (in_w ? fabs(nu - (my_sig > 0.0 ? hi : lo)) : fmax(nu - hi, lo - nu));
-            vbuf[i] = dev == dev ? dev : inf;
-            wcqp::wave_lds_fence();
-            double worst = 0.0;
-#pragma unroll 1
-            for (int j = 6; j < kNV; ++j) worst = fmax(worst, vbuf[j]);
-            if (st_code == WCQP_STATUS_SOLVED && worst > 1e-9) st_code = WCQP_STATUS_NUMERIC;
-            if (st_code == WCQP_STATUS_SOLVED && in_w) nu = my_sig > 0.0 ? hi : lo;
-        }
+            return tp * sig;
+        };
+        gi_active_set<KMAX, L::TCS, L::LDR>(w, i, half, var, lo, hi, tol, prm->max_iter, nu, st_code, it, in_w, my_sig,
+                                            column_of_P);
     }
 
     // ---------------- outputs ---------------------------------------------------------------

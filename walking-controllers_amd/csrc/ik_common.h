@@ -38,6 +38,173 @@ __device__ __forceinline__ double group_bcast(double v) {
 }
 
 
+// xor-butterfly over the 32 lanes of a group (ds_swizzle bit-mask mode: and = 0x1f, xor = M)
+template <int M>
+__device__ __forceinline__ double group_xor(double v) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x1f | (M << 10));
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x1f | (M << 10));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double group_max(double v) {
+    v = fmax(v, group_xor<16>(v)); v = fmax(v, group_xor<8>(v)); v = fmax(v, group_xor<4>(v));
+    v = fmax(v, group_xor<2>(v));  v = fmax(v, group_xor<1>(v));
+    return v;
+}
+__device__ __forceinline__ double group_min(double v) {
+    v = fmin(v, group_xor<16>(v)); v = fmin(v, group_xor<8>(v)); v = fmin(v, group_xor<4>(v));
+    v = fmin(v, group_xor<2>(v));  v = fmin(v, group_xor<1>(v));
+    return v;
+}
+// lowest lane of this 32-lane group whose predicate holds (32 if none)
+__device__ __forceinline__ int group_first(bool pred, int half) {
+    const unsigned m = (unsigned)((__ballot(pred) >> (32 * half)) & 0xffffffffull);
+    return m ? __ffs(m) - 1 : 32;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Goldfarb-Idnani dual active set over the joint-velocity bounds, shared by both IK kernels.
+//
+// Everything is expressed through full-space columns  tau_p = P e_p  of the projected inverse
+// Hessian (supplied by `column_of_P`), so a working-set change never refactorises anything.
+// The k x k system of the active bounds is carried as its EXPLICIT inverse Rinv, updated in
+// O(k^2) by bordering (add) / rank-one downdate (drop); slot a of the working set is owned by
+// lane a (its variable, sign and multiplier live in that lane's registers), so every step is a
+// few lane-parallel passes instead of a serial k^3 factorisation.
+// All control flow is uniform inside a 32-lane group; the two groups of a wave may diverge.
+struct GiScratch {
+    double* Tc;     // [KMAX][TCS]  columns sigma_a P e_{w_a} of the active bounds
+    double* Rinv;   // [KMAX][LDR]
+    double* vbuf;   // [32]
+    double* zbuf;   // [32]
+    double* tpb;    // [32]
+    double* rvec;   // [32]  dual step per slot
+    double* cvec;   // [32]
+    int*    Wi;     // [32]  variable of slot a
+};
+
+template <int KMAX, int TCS, int LDR, class ColumnFn>
+__device__ __forceinline__ void gi_active_set(const GiScratch& w, int i, int half, bool var, double lo, double hi,
+                                              double tol, int max_iter, double& nu, int& st_code, int& it,
+                                              bool& in_w, double& my_sig, ColumnFn&& column_of_P) {
+    const double inf = __builtin_inf();
+    // slot state of lane i (slot index == lane index, slots 0..KMAX-1)
+    bool s_live = false;
+    int s_var = 0;
+    double s_sg = 0.0, s_mu = 0.0;
+    int nW = 0, hiW = 0;
+    if (i < KMAX) {
+        for (int b = 0; b < KMAX; ++b) w.Rinv[i * LDR + b] = 0.0;
+    }
+    wcqp::wave_lds_fence();
+    bool running = st_code == WCQP_STATUS_SOLVED;
+    while (running) {
+        // most violated bound outside the working set
+        const double v_hi = nu - hi, v_lo = lo - nu;
+        const double viol = (var && i >= 6 && !in_w) ? fmax(v_hi, v_lo) : -inf;
+        const double s0 = group_max(viol);
+        if (!(s0 > tol)) break;
+        if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; break; }
+        ++it;
+        const int p = group_first(viol == s0, half);
+        w.zbuf[i] = v_hi >= v_lo ? 1.0 : -1.0;
+        wcqp::wave_lds_fence();
+        const double sig = w.zbuf[p];
+        wcqp::wave_lds_fence();
+        double s = s0;
+        double tp = column_of_P(p, sig);                 // sig * P[i][p] on every variable lane, 0 elsewhere
+        w.tpb[i] = tp;
+        wcqp::wave_lds_fence();
+        const double ppp = sig * w.tpb[p];               // P[p][p] > 0
+        double mu_p = 0.0;
+#pragma unroll 1
+        for (int inner = 0; inner <= KMAX + 1; ++inner) {
+            // dual step r = Rinv c,  c_a = sigma_a tp[w_a]
+            const double c_a = s_live ? s_sg * w.tpb[s_var] : 0.0;
+            w.cvec[i] = c_a;
+            wcqp::wave_lds_fence();
+            double r_a = 0.0;
+            if (s_live) {
+#pragma unroll 1
+                for (int b = 0; b < hiW; ++b) r_a = fma(w.Rinv[i * LDR + b], w.cvec[b], r_a);
+            }
+            w.rvec[i] = r_a;
+            wcqp::wave_lds_fence();
+            // primal step z = tp - sum_a r_a Tc[a]
+            double z = tp;
+#pragma unroll 1
+            for (int a = 0; a < hiW; ++a) z = fma(-w.rvec[a], w.Tc[a * TCS + (var ? i : 0)], z);
+            w.zbuf[i] = z;
+            wcqp::wave_lds_fence();
+            const double nzv = sig * w.zbuf[p];          // Schur complement of the bordered system
+            // a full working set (nW == n - meq) leaves no direction; otherwise dependence shows as
+            // a vanishing Schur complement
+            const double t2 = (nW < KMAX && nzv > 1e-10 * ppp) ? s / nzv : inf;
+            const double ratio = (s_live && r_a > 0.0) ? s_mu / r_a : inf;
+            const double t1 = group_min(ratio);
+            const double t = fmin(t1, t2);
+            if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; running = false; break; }
+            nu = fma(-t, z, nu);
+            s_mu = s_live ? s_mu - t * r_a : s_mu;
+            mu_p += t;
+            s -= t * nzv;
+            if (t2 <= t1) {
+                // full step: p enters the first free slot; Rinv <- bordered inverse (needs r and nzv only)
+                const int n = group_first(i < KMAX && !s_live, half);
+                const double inz = 1.0 / nzv;
+                if (s_live) {
+#pragma unroll 1
+                    for (int b = 0; b < hiW; ++b) w.Rinv[i * LDR + b] = fma(r_a * inz, w.rvec[b], w.Rinv[i * LDR + b]);
+                    w.Rinv[i * LDR + n] = -r_a * inz;
+                }
+                wcqp::wave_lds_fence();
+                if (i == n) {
+#pragma unroll 1
+                    for (int b = 0; b < KMAX; ++b) w.Rinv[n * LDR + b] = (b < hiW) ? -w.rvec[b] * inz : 0.0;
+                    w.Rinv[n * LDR + n] = inz;
+                    s_live = true; s_var = p; s_sg = sig; s_mu = mu_p;
+                    w.Wi[n] = p;
+                }
+                if (var) w.Tc[n * TCS + i] = tp;
+                if (i == p) { in_w = true; my_sig = sig; }
+                ++nW;
+                hiW = hiW > n + 1 ? hiW : n + 1;
+                wcqp::wave_lds_fence();
+                break;
+            }
+            // partial step: the blocking constraint leaves the working set; Rinv <- downdated inverse
+            const int jd = group_first(ratio == t1, half);
+            const int wdrop = w.Wi[jd];
+            const double djj = w.Rinv[jd * LDR + jd];
+            if (s_live && i != jd) {
+                const double f = w.Rinv[i * LDR + jd] / djj;
+#pragma unroll 1
+                for (int b = 0; b < hiW; ++b) w.Rinv[i * LDR + b] = fma(-f, w.Rinv[jd * LDR + b], w.Rinv[i * LDR + b]);
+            }
+            wcqp::wave_lds_fence();
+            if (i < KMAX) w.Rinv[i * LDR + jd] = 0.0;
+            if (i == jd) {
+#pragma unroll 1
+                for (int b = 0; b < KMAX; ++b) w.Rinv[jd * LDR + b] = 0.0;
+                s_live = false; s_mu = 0.0;
+            }
+            if (i == wdrop) { in_w = false; my_sig = 0.0; }
+            --nW;
+            ++it;
+            wcqp::wave_lds_fence();
+        }
+        wcqp::wave_lds_fence();
+    }
+    // certificate: every bound holds and every active bound is tight, else the walk lost accuracy
+    // (near-dependent working set) and the answer must not read SOLVED
+    {
+        const double dev = !(var && i >= 6) ? 0.0
+                         : (in_w ? fabs(nu - (my_sig > 0.0 ? hi : lo)) : fmax(nu - hi, lo - nu));
+        const double worst = group_max(dev == dev ? dev : inf);
+        if (st_code == WCQP_STATUS_SOLVED && worst > 1e-9) st_code = WCQP_STATUS_NUMERIC;
+        if (st_code == WCQP_STATUS_SOLVED && in_w) nu = my_sig > 0.0 ? hi : lo;
+    }
+}
+
 // launch of the null-space kernel (ik2.hip)
 int ik2_launch(const IkDeviceParams* d_prm, bool use_com, int batch,
                const double* JL, const double* JR, const double* JN, const double* JC,
