@@ -1,0 +1,42 @@
+// Self-test of the cross-lane helpers of ik_common.h (DPP/ds_swizzle control words are easy to
+// get wrong and a wrong arg-max would only change pivot choices, not fail a parity test).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include "ik_common.h"
+using namespace wcqp_ik;
+__global__ void k(const double* in, double* omax, double* omin, int* ofirst, double* obc, double* ox16) {
+    const int t = threadIdx.x, half = t >> 5;
+    const double v = in[blockIdx.x * 64 + t];
+    omax[blockIdx.x * 64 + t] = group_max(v);
+    omin[blockIdx.x * 64 + t] = group_min(v);
+    ofirst[blockIdx.x * 64 + t] = group_first(v > 0.5, half);
+    obc[blockIdx.x * 64 + t] = group_bcast<7>(v);
+    ox16[blockIdx.x * 64 + t] = group_xor<16>(v);
+}
+int main() {
+    const int nb = 64, n = nb * 64;
+    std::vector<double> h(n);
+    unsigned long long s = 1;
+    for (auto& x : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; x = (double)(s >> 11) / 9007199254740992.0; }
+    double *d, *a, *b, *e, *f; int* c;
+    hipMalloc(&d, n * 8); hipMalloc(&a, n * 8); hipMalloc(&b, n * 8); hipMalloc(&e, n * 8); hipMalloc(&f, n * 8); hipMalloc(&c, n * 4);
+    hipMemcpy(d, h.data(), n * 8, hipMemcpyHostToDevice);
+    k<<<nb, 64>>>(d, a, b, c, e, f);
+    std::vector<double> ra(n), rb(n), re(n), rf(n); std::vector<int> rc(n);
+    hipMemcpy(ra.data(), a, n * 8, hipMemcpyDeviceToHost); hipMemcpy(rb.data(), b, n * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(re.data(), e, n * 8, hipMemcpyDeviceToHost); hipMemcpy(rf.data(), f, n * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(rc.data(), c, n * 4, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int g = 0; g < n / 32; ++g) {
+        double mx = -1, mn = 2; int first = 32;
+        for (int l = 0; l < 32; ++l) { double x = h[g * 32 + l]; mx = fmax(mx, x); mn = fmin(mn, x); if (x > 0.5 && first == 32) first = l; }
+        for (int l = 0; l < 32; ++l) {
+            const int t = g * 32 + l;
+            if (ra[t] != mx || rb[t] != mn || rc[t] != first || re[t] != h[g * 32 + 7] || rf[t] != h[g * 32 + (l ^ 16)]) ++bad;
+        }
+    }
+    std::printf("dpp_selftest: %s (%d mismatches of %d)\n", bad ? "FAIL" : "ok", bad, n);
+    return bad != 0;
+}

@@ -185,11 +185,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const long long bits = (__double_as_longlong(fabs(a[r])) & ~31ll) | (long long)(31 - i);
                 key = __longlong_as_double(bits);
             }
-            key = fmax(key, group_xor<16>(key));
-            key = fmax(key, group_xor<8>(key));
-            key = fmax(key, group_xor<4>(key));
-            key = fmax(key, group_xor<2>(key));
-            key = fmax(key, group_xor<1>(key));
+            key = group_max(key);
             const int pl = 31 - (int)(__double_as_longlong(key) & 31ll);
             double* cb = cbase + 16 * (r & 1);
             if (i == pl) {

@@ -45,14 +45,32 @@ __device__ __forceinline__ double group_xor(double v) {
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x1f | (M << 10));
     return __hiloint2double(hi, lo);
 }
+// One DPP move of both halves of a double (dpp_ctrl must be a literal): quad_perm 0x00-0xff,
+// row_mirror 0x140, row_half_mirror 0x141.  ~3 VALU instructions and no LDS-pipe round trip,
+// against ~70 cycles for a ds_swizzle pair.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce over the 32 lanes of a group: four DPP steps inside each row of 16 (xor 1, xor 2 as
+// quad permutes; then half-mirror and mirror, which pair up quads / octets that already agree),
+// one crossbar swap between the two rows
 __device__ __forceinline__ double group_max(double v) {
-    v = fmax(v, group_xor<16>(v)); v = fmax(v, group_xor<8>(v)); v = fmax(v, group_xor<4>(v));
-    v = fmax(v, group_xor<2>(v));  v = fmax(v, group_xor<1>(v));
+    v = fmax(v, dpp_move<0xB1>(v));     // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_move<0x4E>(v));     // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_move<0x141>(v));    // row_half_mirror
+    v = fmax(v, dpp_move<0x140>(v));    // row_mirror
+    v = fmax(v, group_xor<16>(v));
     return v;
 }
 __device__ __forceinline__ double group_min(double v) {
-    v = fmin(v, group_xor<16>(v)); v = fmin(v, group_xor<8>(v)); v = fmin(v, group_xor<4>(v));
-    v = fmin(v, group_xor<2>(v));  v = fmin(v, group_xor<1>(v));
+    v = fmin(v, dpp_move<0xB1>(v));
+    v = fmin(v, dpp_move<0x4E>(v));
+    v = fmin(v, dpp_move<0x141>(v));
+    v = fmin(v, dpp_move<0x140>(v));
+    v = fmin(v, group_xor<16>(v));
     return v;
 }
 // lowest lane of this 32-lane group whose predicate holds (32 if none)
