@@ -23,8 +23,9 @@ namespace {
 using namespace wcqp_ik;
 
 constexpr int kLDF = 16;      // leading dim of a stored F column (meq <= 15 entries)
+typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <bool USE_COM>
+template <bool USE_COM, bool USE_MFMA>
 struct Ik2Layout {
     static constexpr int MEQ = USE_COM ? 15 : 12;       // equality rows
     static constexpr int NCOST = USE_COM ? 3 : 6;       // cost rows: [J_com;] J_neck
@@ -36,14 +37,22 @@ struct Ik2Layout {
     static constexpr int OFF_FK = 0;                    // [NK][kLDF]   F columns by compact index (slot NN = b')
     static constexpr int OFF_P = OFF_FK + NK * kLDF;
     // phase A (set-up)
+    // MFMA variant: K-major operand tables X^T, Y^T [20][16] of the reduced-Hessian Gram product
+    // overlay the state block and the pivot columns (both dead by then); the 16x16 result tile
+    // [16][LDH] overlays X^T again (its writes depend on the MFMA results, i.e. follow every read)
+    static constexpr int LDH = 18;
+    static constexpr int OFF_XT = OFF_P;
+    static constexpr int OFF_YT = OFF_XT + 20 * 16;
+    static constexpr int OFF_HM = OFF_XT;
     static constexpr int OFF_ST = OFF_P;                // [112] state + q
     static constexpr int OFF_CB = OFF_ST + 112;         // [2][16] pivot column, double-buffered
-    static constexpr int OFF_RD = OFF_CB + 32;          // [16][8] per row r: {D, g, cost-row entries} of its basic variable
-    static constexpr int OFF_WNZ = OFF_RD + 16 * 8;     // [NK][NCOST + (NCOST & 1)]
+    static constexpr int OFF_RD = (USE_MFMA ? OFF_YT + 20 * 16 : OFF_CB + 32);   // [16][8] per row r: {D, g, cost-row entries} of its basic variable
+    static constexpr int OFF_WNZ = OFF_RD + 16 * 8;     // [NK][NCOST + (NCOST & 1)]  (VALU variant only)
     static constexpr int LDW = NCOST + (NCOST & 1);
-    static constexpr int OFF_COL = OFF_WNZ + NK * LDW;  // [2][32] sweep columns, double-buffered
+    static constexpr int OFF_COL = OFF_WNZ + (USE_MFMA ? 0 : NK * LDW);  // [2][32] sweep columns, double-buffered
     static constexpr int OFF_GR = OFF_COL + 64;         // [32] reduced gradient / x_N by compact index
     static constexpr int END_A = OFF_GR + 32;
+    static_assert(!USE_MFMA || (USE_COM && NK <= 16 && MEQ + NCOST <= 20), "one 16x16x20 MFMA tile");
     // phase B (active set) reuses the phase-A area
     static constexpr int OFF_TC = OFF_P;                // [KMAX][TCS]
     static constexpr int LDR = KMAX | 1;                // odd leading dim: row-per-lane accesses spread over banks
@@ -61,8 +70,8 @@ struct Ik2Layout {
     static constexpr int PER_INST = ((OFF_B + 16) + 1) & ~1;
 };
 
-template <bool USE_COM>
-__global__ __launch_bounds__(64, 3)
+template <bool USE_COM, bool USE_MFMA>
+__global__ __launch_bounds__(64, USE_MFMA ? 2 : 3)
 void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
                 const double* __restrict__ JN, const double* __restrict__ JC,
@@ -71,7 +80,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out)
 {
-    using L = Ik2Layout<USE_COM>;
+    using L = Ik2Layout<USE_COM, USE_MFMA>;
     constexpr int MEQ = L::MEQ, NCOST = L::NCOST, NN = L::NN, NK = L::NK, KMAX = L::KMAX, LDW = L::LDW;
     (void)NK;
     __shared__ __attribute__((aligned(16))) double smem[2][L::PER_INST];
@@ -225,6 +234,10 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     if (rowlane) {
 #pragma unroll
         for (int r = 0; r < MEQ; ++r) Fk[kap_i * kLDF + r] = a[r];
+        if constexpr (USE_MFMA) {
+#pragma unroll
+            for (int r = 0; r < MEQ; ++r) S[L::OFF_YT + r * 16 + kap_i] = a[r];     // Y^T rows 0..MEQ-1 = F
+        }
     }
     wcqp::wave_lds_fence();
     // one pass over the rows: nz = column of N Z (rhs lane: -N x_p), g_r partial, a := F_j[r] D_B[r]
@@ -258,14 +271,65 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 w[3 + s] = prm->Wn[3 * s] * nz[3] + prm->Wn[3 * s + 1] * nz[4] + prm->Wn[3 * s + 2] * nz[5];
             }
         }
-        if (rowlane) {
+        if constexpr (USE_MFMA) {
+            if (rowlane) {
 #pragma unroll
-            for (int s = 0; s < NCOST; ++s) wnz[kap_i * LDW + s] = w[s];
+                for (int r = 0; r < MEQ; ++r) S[L::OFF_XT + r * 16 + kap_i] = a[r];   // X^T rows 0..MEQ-1 = F D_B
+#pragma unroll
+                for (int s = 0; s < NCOST; ++s) { S[L::OFF_XT + (MEQ + s) * 16 + kap_i] = nz[s]; S[L::OFF_YT + (MEQ + s) * 16 + kap_i] = w[s]; }
+            }
+            // zero padding: reduction rows MEQ+NCOST..19 and the unused slot column 15
+            if (i < 16) {
+#pragma unroll
+                for (int r = MEQ + NCOST; r < 20; ++r) { S[L::OFF_XT + r * 16 + i] = 0.0; S[L::OFF_YT + r * 16 + i] = 0.0; }
+            }
+            if (i < 20) {
+#pragma unroll
+                for (int c = NK; c < 16; ++c) { S[L::OFF_XT + i * 16 + c] = 0.0; S[L::OFF_YT + i * 16 + c] = 0.0; }
+            }
+        } else {
+            if (rowlane) {
+#pragma unroll
+                for (int s = 0; s < NCOST; ++s) wnz[kap_i * LDW + s] = w[s];
+            }
         }
     }
     wcqp::wave_lds_fence();
     double Hr[NK];
     const double fmask = free_var ? 1.0 : 0.0;
+    if constexpr (USE_MFMA) {
+        // The one genuinely dense contraction of the path: the 15 x 15 Gram product
+        //   [Hr | h_rhs] = X Y',   X = [F D_B | (N Z)'],  Y = [F | (W N Z)'],  K = 18 (padded to 20)
+        // is exactly one 16x16 fp64 MFMA tile per instance: 5 x v_mfma_f64_16x16x4 instead of
+        // 270 VALU FMAs + 150 LDS broadcasts per instance pair.  All 64 lanes feed each
+        // instance's tile (A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]).
+        const int mk = lane & 15, mq = lane >> 4;
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double* x0 = smem[0] + L::OFF_XT; const double* y0 = smem[0] + L::OFF_YT;
+        const double* x1 = smem[1] + L::OFF_XT; const double* y1 = smem[1] + L::OFF_YT;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int o = (4 * s + mq) * 16 + mk;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[o], y0[o], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[o], y1[o], acc1, 0, 0, 0);
+        }
+        // C/D layout of the f64 tile: col = lane & 15, row = (lane >> 4) + 4 * reg
+        double* h0 = smem[0] + L::OFF_HM; double* h1 = smem[1] + L::OFF_HM;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            h0[(mq + 4 * reg) * L::LDH + mk] = acc0[reg];
+            h1[(mq + 4 * reg) * L::LDH + mk] = acc1[reg];
+        }
+        wcqp::wave_lds_fence();
+        const double* hrow = S + L::OFF_HM + (kap_i < 16 ? kap_i : 15) * L::LDH;
+#pragma unroll
+        for (int k = 0; k < NK; k += 2) {
+            const double2 h2 = *reinterpret_cast<const double2*>(hrow + k);
+            Hr[k] = fmask * (h2.x + (k == kap_i ? Di : 0.0));
+            if (k + 1 < NK) Hr[k + 1] = fmask * (h2.y + (k + 1 == kap_i ? Di : 0.0));
+        }
+        wcqp::wave_lds_fence();
+    } else {
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         double acc = 0.0;
@@ -285,6 +349,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         // into a branch and hoisting every LDS read of the loop in front of it (they then spill)
         Hr[k] = fmask * (acc + (k == kap_i ? Di : 0.0));
         wcqp::pin_result(Hr[k]);
+    }
     }
     gr -= Hr[NN];               // g_r = g_j - F_j' g_B - (b'-dependent column)
 
@@ -416,16 +481,19 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 
 namespace wcqp_ik {
 
-int ik2_launch(const IkDeviceParams* d_prm, bool use_com, int batch,
+int ik2_launch(const IkDeviceParams* d_prm, bool use_com, bool use_mfma, int batch,
                const double* JL, const double* JR, const double* JN, const double* JC,
                const double* q, const double* state, double* dq, int* status,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
     const unsigned grid = (unsigned)((batch + 1) / 2);
-    if (use_com)
-        hipLaunchKernelGGL(ik2_kernel<true>, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+    if (use_com && use_mfma)
+        hipLaunchKernelGGL((ik2_kernel<true, true>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+                           dq, status, alo, aup, ferr, iters);
+    else if (use_com)
+        hipLaunchKernelGGL((ik2_kernel<true, false>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
                            dq, status, alo, aup, ferr, iters);
     else
-        hipLaunchKernelGGL(ik2_kernel<false>, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+        hipLaunchKernelGGL((ik2_kernel<false, false>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
                            dq, status, alo, aup, ferr, iters);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;

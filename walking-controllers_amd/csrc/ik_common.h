@@ -224,7 +224,7 @@ __device__ __forceinline__ void gi_active_set(const GiScratch& w, int i, int hal
 }
 
 // launch of the null-space kernel (ik2.hip)
-int ik2_launch(const IkDeviceParams* d_prm, bool use_com, int batch,
+int ik2_launch(const IkDeviceParams* d_prm, bool use_com, bool use_mfma, int batch,
                const double* JL, const double* JR, const double* JN, const double* JC,
                const double* q, const double* state, double* dq, int* status,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream);
