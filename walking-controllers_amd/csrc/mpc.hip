@@ -32,6 +32,19 @@ __device__ const unsigned char kPairE[28] = {0,0,0,0,0,0,0, 1,1,1,1,1,1, 2,2,2,2
 __device__ const unsigned char kPairF[28] = {1,2,3,4,5,6,7, 2,3,4,5,6,7, 3,4,5,6,7, 4,5,6,7, 5,6,7, 6,7, 7};
 constexpr int kNumCand = 1 + 8 + 28;
 
+// One DPP move of both halves of a double inside a row of 16 lanes (= one instance here).
+template <int CTRL>
+__device__ __forceinline__ double row_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int row_move(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// the four butterfly partners inside a row: xor 1, xor 2 (quad permutes), then half-mirror and
+// mirror, which pair quads / octets whose lanes already agree
+#define WCQP_ROW_STEPS(X) X(0xB1) X(0x4E) X(0x141) X(0x140)
+
 struct MpcDeviceConsts {
     const double* Gr;     // (N+1) x 2 x 2
     double Gx[4], Gu[4], S0[4];
@@ -64,12 +77,25 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
     const double2* rp = reinterpret_cast<const double2*>(ref) + inst * ref_stride + (ref_start ? *ref_start : 0);
     const double2* gp = reinterpret_cast<const double2*>(c.Gr);
     double ux = 0.0, uy = 0.0;
-    for (int i = t; i <= c.N; i += kLanesPerInstance) {
-        const int ir = i < ref_len ? i : ref_len - 1;     // MPCSolver.cpp:200-214 (constant tail)
-        const double2 r  = rp[ir];
-        const double2 g0 = gp[2 * i], g1 = gp[2 * i + 1];
-        ux = fma(g0.x, r.x, fma(g0.y, r.y, ux));
-        uy = fma(g1.x, r.x, fma(g1.y, r.y, uy));
+    // 64 stages per pass: the four reference loads of a lane (stages t, t+16, t+32, t+48) are
+    // issued back to back before any is consumed, so one HBM round trip covers the whole window
+    // of the N = 50 benchmark instead of four serialized ones
+    for (int base = 0; base <= c.N; base += 4 * kLanesPerInstance) {
+        double2 r[4], g0[4], g1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + t + k * kLanesPerInstance;
+            const int ic = i <= c.N ? i : c.N;                // clamped: stays in bounds, weight zeroed below
+            const int ir = ic < ref_len ? ic : ref_len - 1;   // MPCSolver.cpp:200-214 (constant tail)
+            r[k] = rp[ir];
+            g0[k] = gp[2 * ic]; g1[k] = gp[2 * ic + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double m = (base + t + k * kLanesPerInstance) <= c.N ? 1.0 : 0.0;
+            ux = fma(m * g0[k].x, r[k].x, fma(m * g0[k].y, r[k].y, ux));
+            uy = fma(m * g1[k].x, r[k].x, fma(m * g1[k].y, r[k].y, uy));
+        }
     }
     if (t == 0) {
         const double2 xs = reinterpret_cast<const double2*>(x0)[inst];
@@ -80,17 +106,17 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
     // hull rows -> LDS (lanes 0..7 of the instance own one row each)
     int nc = hull_nc[inst];
     nc = nc < 0 ? 0 : (nc > WCQP_HULL_ROWS ? WCQP_HULL_ROWS : nc);
+    double rax = 0.0, ray = 0.0, rb = 0.0, rn = 0.0;    // this lane's own hull row (lanes 0..7)
     if (t < WCQP_HULL_ROWS) {
         const double2 a = reinterpret_cast<const double2*>(hull_A)[inst * WCQP_HULL_ROWS + t];
-        const double  b = hull_b[inst * WCQP_HULL_ROWS + t];
-        s_hull[sub][t][0] = a.x; s_hull[sub][t][1] = a.y; s_hull[sub][t][2] = b;
-        s_hull[sub][t][3] = sqrt(a.x * a.x + a.y * a.y);
+        rb = hull_b[inst * WCQP_HULL_ROWS + t];
+        rax = a.x; ray = a.y; rn = sqrt(a.x * a.x + a.y * a.y);
+        s_hull[sub][t][0] = rax; s_hull[sub][t][1] = ray; s_hull[sub][t][2] = rb; s_hull[sub][t][3] = rn;
     }
-#pragma unroll
-    for (int m = kLanesPerInstance / 2; m >= 1; m >>= 1) {   // butterfly: every lane ends with the same sum
-        ux += __shfl_xor(ux, m, kLanesPerInstance);
-        uy += __shfl_xor(uy, m, kLanesPerInstance);
-    }
+    // butterfly over the row (DPP, no LDS-pipe round trips): every lane ends with the same sum
+#define WCQP_SUM_STEP(C) ux += row_move<C>(ux); uy += row_move<C>(uy);
+    WCQP_ROW_STEPS(WCQP_SUM_STEP)
+#undef WCQP_SUM_STEP
     wcqp::wave_lds_fence();
 
     // ---- projection onto the polygon in the Sigma0^-1 metric --------------------------
@@ -99,6 +125,14 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
     double best_x = ux, best_y = uy;
     unsigned best_mask = 0;
     int best_id = kNumCand;
+    // Early out (wave-uniform): when the unconstrained optimum of every instance of this wave
+    // already satisfies its hull rows, candidate 0 wins by construction (cost 0, lowest id) and the
+    // 37-candidate enumeration is skipped.  Same feasibility test as the enumeration applies to
+    // candidate 0, so the result is identical either way.
+    const bool row_violated = t < nc && (rax * ux + ray * uy - rb) > c.feas_tol;
+    if (__ballot(row_violated) == 0ull) {
+        best_cost = 0.0; best_id = 0;
+    } else
     for (int id = t; id < kNumCand; id += kLanesPerInstance) {
         int e = -1, f = -1;
         if (id >= 1 && id <= 8) e = id - 1;
@@ -115,7 +149,7 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
             mask = 1u << e;
             if (f < 0) {
                 ok = ree > 0.0;
-                const double mu = ok ? re / ree : 0.0;
+                const double mu = ok ? re * wcqp::fast_rcp(ree) : 0.0;
                 px = ux - sex * mu; py = uy - sey * mu;
                 cost = mu * re;
             } else {
@@ -126,7 +160,7 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
                 const double rf  = afx * ux + afy * uy - s_hull[sub][f][2];
                 const double det = ree * rff - ref_ * ref_;
                 ok = det > 1e-12 * ree * rff;                 // parallel rows have no vertex
-                const double idet = ok ? 1.0 / det : 0.0;
+                const double idet = ok ? wcqp::fast_rcp(det) : 0.0;
                 const double mue = (rff * re - ref_ * rf) * idet;
                 const double muf = (ree * rf - ref_ * re) * idet;
                 px = ux - sex * mue - sfx * muf; py = uy - sey * mue - sfy * muf;
@@ -142,27 +176,22 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
             best_cost = cost; best_x = px; best_y = py; best_mask = mask; best_id = id;
         }
     }
-#pragma unroll
-    for (int m = kLanesPerInstance / 2; m >= 1; m >>= 1) {
-        const double oc = __shfl_xor(best_cost, m, kLanesPerInstance);
-        const double ox = __shfl_xor(best_x, m, kLanesPerInstance);
-        const double oy = __shfl_xor(best_y, m, kLanesPerInstance);
-        const unsigned om = __shfl_xor(best_mask, m, kLanesPerInstance);
-        const int oi = __shfl_xor(best_id, m, kLanesPerInstance);
-        if (oc < best_cost || (oc == best_cost && oi < best_id)) {
-            best_cost = oc; best_x = ox; best_y = oy; best_mask = om; best_id = oi;
-        }
-    }
+#define WCQP_MIN_STEP(C) {                                                              \
+        const double oc = row_move<C>(best_cost), ox = row_move<C>(best_x), oy = row_move<C>(best_y); \
+        const int om = row_move<C>((int)best_mask), oi = row_move<C>(best_id);                 \
+        if (oc < best_cost || (oc == best_cost && oi < best_id)) {                             \
+            best_cost = oc; best_x = ox; best_y = oy; best_mask = (unsigned)om; best_id = oi;  \
+        } }
+    WCQP_ROW_STEPS(WCQP_MIN_STEP)
+#undef WCQP_MIN_STEP
+    // signed distance to the hull boundary (computeMargin semantics): every row lane evaluates its
+    // own row, row-min by DPP
+    double margin = (t < nc && rn > 0.0) ? (rb - rax * best_x - ray * best_y) / rn : std::numeric_limits<double>::infinity();
+#define WCQP_MARGIN_STEP(C) margin = fmin(margin, row_move<C>(margin));
+    WCQP_ROW_STEPS(WCQP_MARGIN_STEP)
+#undef WCQP_MARGIN_STEP
     if (t == 0 && live) {
         int st = best_id < kNumCand ? WCQP_STATUS_SOLVED : WCQP_STATUS_INFEASIBLE;
-        double margin = std::numeric_limits<double>::infinity();
-        for (int k = 0; k < nc; ++k) {
-            const double nrm = s_hull[sub][k][3];
-            if (nrm > 0.0) {
-                const double m_k = (s_hull[sub][k][2] - s_hull[sub][k][0] * best_x - s_hull[sub][k][1] * best_y) / nrm;
-                margin = m_k < margin ? m_k : margin;
-            }
-        }
         // WalkingController::solve: computeMargin(u0) < -tolerance => failure (cpp:513-517)
         if (st == WCQP_STATUS_SOLVED && margin < -c.hull_tol) st = WCQP_STATUS_OUTSIDE_HULL;
         reinterpret_cast<double2*>(u0_out)[inst] = make_double2(best_x, best_y);
