@@ -130,10 +130,10 @@ int wcqp_mpc_solve_host(wcqp_mpc_t h, int32_t batch,
 #define WCQP_IK_FORM_QPOASES 0   /* bounds enforced, kappa = 1, feet always corrected        */
 #define WCQP_IK_ALG_DEFAULT   0
 #define WCQP_IK_ALG_SWEEP     1
-#define WCQP_IK_ALG_NULLSPACE 2        /* null-space kernel, reduced Hessian on the fp64 VALU (the default)  */
-#define WCQP_IK_ALG_NULLSPACE_MFMA 3   /* same, reduced-Hessian Gram product on v_mfma_f64_16x16x4; measured
-                                          equal-to-slower than 2 on MI355X (fp64 MFMA peak == fp64 VALU peak),
-                                          kept selectable; needs use_com_as_constraint, else runs as 2       */
+#define WCQP_IK_ALG_NULLSPACE 2        /* null-space kernel, reduced Hessian on the fp64 VALU                 */
+#define WCQP_IK_ALG_NULLSPACE_MFMA 3   /* same, reduced-Hessian Gram product as one v_mfma_f64_16x16x4 tile per
+                                          instance: ~5 % faster than 2 in interleaved A/B runs (the default);
+                                          needs use_com_as_constraint (one 16x16 tile), else runs as 2        */
 #define WCQP_IK_FORM_OSQP    1   /* joint-limit rows are zero rows (never bind), extra
                                     k_attFoot on the neck gradient term, zero-twist rule
                                                                */
@@ -153,7 +153,7 @@ typedef struct wcqp_ik_params {
     double  k_pos_com, k_pos_foot, k_att_foot, k_neck;
     double  rho;                         /* weight of the A'A term that regularises H; 0 -> 1  */
     double  tol;                         /* bound-violation tolerance; 0 -> 1e-12              */
-    int32_t algorithm;                   /* WCQP_IK_ALG_*: 0 -> default (2), 1 = sweep on H + rho A'A (csrc/ik.hip),
+    int32_t algorithm;                   /* WCQP_IK_ALG_*: 0 -> default (3), 1 = sweep on H + rho A'A (csrc/ik.hip),
                                             2 / 3 = null-space (csrc/ik2.hip) without / with MFMA; same optimum */
 } wcqp_ik_params;
 

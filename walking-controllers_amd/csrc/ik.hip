@@ -42,14 +42,12 @@ struct IkLayout {
     static constexpr int NC1 = MEQ + 1;                 // columns of G+ = [A' g~]
     static constexpr int KMAX = kNV - MEQ;              // most bounds that can be active at once
     static constexpr int LDS_S = MEQ + (MEQ & 1);       // leading dim of Sinv rows
-    static constexpr int TCS = 30;                      // stride of one stored column of P (29 live lanes)
     // ---- per-instance LDS map (doubles) ----
     static constexpr int OFF_CR = 0;                    // [18][kLD]   phases 1-5
     static constexpr int OFF_GM = OFF_CR + kRows * kLD; // [29][kLDG]  phases 4-5
     static constexpr int END_MAT = OFF_GM + kNV * kLDG;
     // phase 6 reuses the matrix area
-    static constexpr int OFF_TC = 0;                    // [KMAX][TCS]
-    static constexpr int OFF_SV = OFF_TC + KMAX * TCS;  // [MEQ][LDS_S]
+    static constexpr int OFF_SV = 0;                    // [MEQ][LDS_S]
     static constexpr int LDR = KMAX | 1;
     static constexpr int OFF_RINV = OFF_SV + MEQ * LDS_S;   // [KMAX][LDR]
     static constexpr int OFF_GROW = OFF_RINV + KMAX * LDR + ((KMAX * LDR) & 1); // [16] one row of G
@@ -342,7 +340,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         double* Sv = S + L::OFF_SV;
         double* rowbuf = S + L::OFF_V3;
         double* grow = S + L::OFF_GROW;
-        const GiScratch w{S + L::OFF_TC, S + L::OFF_RINV, S + L::OFF_V0, S + L::OFF_V1, S + L::OFF_V2,
+        const GiScratch w{S + L::OFF_RINV, S + L::OFF_V0, S + L::OFF_V1, S + L::OFF_V2,
                           S + L::OFF_R, S + L::OFF_C, reinterpret_cast<int*>(S + L::OFF_WI)};
         // E = G Sinv (row i in registers): publish Sinv rows once
         if (i < MEQ) {
@@ -374,7 +372,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             wcqp::wave_lds_fence();
             return tp * sig;
         };
-        gi_active_set<KMAX, L::TCS, L::LDR>(w, i, half, var, lo, hi, tol, prm->max_iter, nu, st_code, it, in_w, my_sig,
+        gi_active_set<KMAX, L::LDR>(w, i, half, var, lo, hi, tol, prm->max_iter, nu, st_code, it, in_w, my_sig,
                                             column_of_P);
     }
 
@@ -496,7 +494,7 @@ int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
     const int rc = ensure_device(h);
     if (rc != WCQP_OK) return rc;
     if (h->p.algorithm != WCQP_IK_ALG_SWEEP)
-        return wcqp_ik::ik2_launch(h->d_prm, h->p.use_com_as_constraint != 0, h->p.algorithm == WCQP_IK_ALG_NULLSPACE_MFMA, batch, J_left, J_right, J_neck, J_com,
+        return wcqp_ik::ik2_launch(h->d_prm, h->p.use_com_as_constraint != 0, h->p.algorithm != WCQP_IK_ALG_NULLSPACE, batch, J_left, J_right, J_neck, J_com,
                                    q, state, dq, status, active_lower, active_upper, foot_err, iters, (hipStream_t)stream);
     const unsigned grid = (unsigned)((batch + 1) / 2);
     if (h->p.use_com_as_constraint)

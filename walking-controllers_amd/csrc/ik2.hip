@@ -22,6 +22,16 @@ namespace {
 
 using namespace wcqp_ik;
 
+// Diagnostic builds only (tools/stamps.sh): s_memtime at phase boundaries, written by lane 0 of
+// each wave into the foot-error buffer (never an output in that build).  No stamp exists in the
+// product build.
+#ifdef WCQP_IK_STAMPS
+#define WCQP_STAMP(k) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+                           if (lane == 0) reinterpret_cast<unsigned long long*>(ferr_out)[(size_t)blockIdx.x * 16 + (k)] = t__; } while (0)
+#else
+#define WCQP_STAMP(k) do { } while (0)
+#endif
+
 constexpr int kLDF = 16;      // leading dim of a stored F column (meq <= 15 entries)
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -32,7 +42,6 @@ struct Ik2Layout {
     static constexpr int NN = kNV - MEQ;                // free (non-basic) variables
     static constexpr int NK = NN + 1;                   // compact slots: free variables + the rhs lane
     static constexpr int KMAX = NN;
-    static constexpr int TCS = 30;
     // persistent
     static constexpr int OFF_FK = 0;                    // [NK][kLDF]   F columns by compact index (slot NN = b')
     static constexpr int OFF_P = OFF_FK + NK * kLDF;
@@ -54,9 +63,8 @@ struct Ik2Layout {
     static constexpr int END_A = OFF_GR + 32;
     static_assert(!USE_MFMA || (USE_COM && NK <= 16 && MEQ + NCOST <= 20), "one 16x16x20 MFMA tile");
     // phase B (active set) reuses the phase-A area
-    static constexpr int OFF_TC = OFF_P;                // [KMAX][TCS]
     static constexpr int LDR = KMAX | 1;                // odd leading dim: row-per-lane accesses spread over banks
-    static constexpr int OFF_RINV = OFF_TC + KMAX * TCS;// [KMAX][LDR]
+    static constexpr int OFF_RINV = OFF_P;              // [KMAX][LDR]
     static constexpr int OFF_V0 = OFF_RINV + KMAX * LDR + ((KMAX * LDR) & 1);
     static constexpr int OFF_V1 = OFF_V0 + 32;          // sign / z
     static constexpr int OFF_V2 = OFF_V1 + 32;          // tp
@@ -71,7 +79,8 @@ struct Ik2Layout {
 };
 
 template <bool USE_COM, bool USE_MFMA>
-__global__ __launch_bounds__(64, USE_MFMA ? 2 : 3)
+// 2 waves/SIMD: at 3 the allocator spills ~50 B/lane to scratch, which costs more than the extra wave buys
+__global__ __launch_bounds__(64, 2)
 void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
                 const double* __restrict__ JN, const double* __restrict__ JC,
@@ -99,6 +108,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const bool var = i < kNV;
     const bool rhs_lane = i == kNV;
 
+    WCQP_STAMP(0);
     // ---------------- phase 0: loads (column i of every task Jacobian) -------------------
     double a[MEQ];          // column i of A = [J_left; J_right; (J_com)]; on lane 29: b
     double cn[NCOST];       // column i of the cost rows [ (J_com;) J_neck ]
@@ -130,6 +140,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
     wcqp::wave_lds_fence();
 
+    WCQP_STAMP(1);
     // ---------------- phase 1: task rhs b (lane r < MEQ) and gradient g ------------------
     const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
     double b_mine = 0.0;
@@ -178,6 +189,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         for (int r = 0; r < MEQ; ++r) a[r] = bvec[r];
     }
 
+    WCQP_STAMP(2);
     // ---------------- phase 2: Gauss-Jordan with column pivoting --------------------------
     bool basic = false;
     int myrow = 0;
@@ -186,16 +198,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         double* cbase = S + L::OFF_CB;
 #pragma unroll
         for (int r = 0; r < MEQ; ++r) {
-            // arg-max of |a[r]| over the free variable lanes: the key keeps the magnitude's top
-            // 59 bits and carries 31 - lane in the low 5, so one v_max_f64 per butterfly step
-            // yields both the pivot lane and a deterministic (lowest-lane) tie-break
-            double key = 0.0;
-            if (var && !basic) {
-                const long long bits = (__double_as_longlong(fabs(a[r])) & ~31ll) | (long long)(31 - i);
-                key = __longlong_as_double(bits);
-            }
-            key = group_max(key);
-            const int pl = 31 - (int)(__double_as_longlong(key) & 31ll);
+            const int pl = group_argmax_abs(a[r], var && !basic, i);
             double* cb = cbase + 16 * (r & 1);
             if (i == pl) {
                 basic = true; myrow = r;
@@ -223,6 +226,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const bool rowlane = free_var || rhs_lane;          // lanes that own a row of [Hr | h_rhs]
     ok = ok && (__popc(gm) == NN);
 
+    WCQP_STAMP(3);
     // ---------------- phase 3: reduced Hessian rows ---------------------------------------
     double* rd = S + L::OFF_RD;
     double* wnz = S + L::OFF_WNZ;
@@ -295,6 +299,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         }
     }
     wcqp::wave_lds_fence();
+    WCQP_STAMP(4);
     double Hr[NK];
     const double fmask = free_var ? 1.0 : 0.0;
     if constexpr (USE_MFMA) {
@@ -353,6 +358,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
     gr -= Hr[NN];               // g_r = g_j - F_j' g_B - (b'-dependent column)
 
+    WCQP_STAMP(5);
     // ---------------- phase 4: Hr^-1 (sweep over the NN compact pivots), x_N, x_B ---------
     {
         double* col = S + L::OFF_COL;
@@ -382,6 +388,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             wcqp::wave_lds_fence();
         }
     }
+    WCQP_STAMP(6);
     // Hr now holds -(Hr^-1) rows on the free lanes
     double* grv = S + L::OFF_GR;
     if (rowlane) grv[kap_i] = gr;
@@ -401,6 +408,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
     wcqp::wave_lds_fence();
 
+    WCQP_STAMP(7);
     // ---------------- phase 5: joint-velocity bounds (qpOASES form) ------------------------
     int st_code = ok ? WCQP_STATUS_SOLVED : WCQP_STATUS_NUMERIC;
     int it = 0;
@@ -410,7 +418,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const double tol = prm->tol;
     const bool need = !osqp_form && var && i >= 6 && fmax(nu - hi, lo - nu) > tol;
     if (__ballot(need) != 0ull) {
-        const GiScratch w{S + L::OFF_TC, S + L::OFF_RINV, S + L::OFF_V0, S + L::OFF_V1, S + L::OFF_V2,
+        const GiScratch w{S + L::OFF_RINV, S + L::OFF_V0, S + L::OFF_V1, S + L::OFF_V2,
                           S + L::OFF_R, S + L::OFF_C, reinterpret_cast<int*>(S + L::OFF_WI)};
         double* tkb = S + L::OFF_V3;
         int* info = reinterpret_cast<int*>(S + L::OFF_INFO);
@@ -447,10 +455,11 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             wcqp::wave_lds_fence();
             return tp * sig;
         };
-        gi_active_set<KMAX, L::TCS, L::LDR>(w, i, half, var, lo, hi, tol, prm->max_iter, nu, st_code, it, in_w, my_sig,
+        gi_active_set<KMAX, L::LDR>(w, i, half, var, lo, hi, tol, prm->max_iter, nu, st_code, it, in_w, my_sig,
                                             column_of_P);
     }
 
+    WCQP_STAMP(8);
     // ---------------- outputs ---------------------------------------------------------------
     const unsigned long long bu = __ballot(in_w && my_sig > 0.0);
     const unsigned long long bl = __ballot(in_w && my_sig < 0.0);
@@ -463,6 +472,10 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             if (iters_out) iters_out[inst] = it;
         }
     }
+#ifdef WCQP_IK_STAMPS
+    WCQP_STAMP(9);
+    return;
+#endif
     if (ferr_out) {
         double* nub = S + L::OFF_FK;                 // F is dead now
         wcqp::wave_lds_fence();

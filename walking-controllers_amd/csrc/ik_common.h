@@ -73,6 +73,19 @@ __device__ __forceinline__ double group_min(double v) {
     v = fmin(v, group_xor<16>(v));
     return v;
 }
+// Lane of the largest |v| among the candidate lanes of a 32-lane group (ties: lowest lane).
+// Pivot choice only needs the magnitude to float precision, so the search runs on a 32-bit key
+// (float bits with 31 - lane in the low 5) and each butterfly step is ONE DPP-fused v_max_u32.
+__device__ __forceinline__ int group_argmax_abs(double v, bool candidate, int i) {
+    unsigned key = candidate ? ((__float_as_uint((float)fabs(v)) & ~31u) | (unsigned)(31 - i)) : 0u;
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x141, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x140, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_ds_swizzle((int)key, 0x1f | (16 << 10)));
+    return 31 - (int)(key & 31u);
+}
+
 // lowest lane of this 32-lane group whose predicate holds (32 if none)
 __device__ __forceinline__ int group_first(bool pred, int half) {
     const unsigned m = (unsigned)((__ballot(pred) >> (32 * half)) & 0xffffffffull);
@@ -90,7 +103,6 @@ __device__ __forceinline__ int group_first(bool pred, int half) {
 // few lane-parallel passes instead of a serial k^3 factorisation.
 // All control flow is uniform inside a 32-lane group; the two groups of a wave may diverge.
 struct GiScratch {
-    double* Tc;     // [KMAX][TCS]  columns sigma_a P e_{w_a} of the active bounds
     double* Rinv;   // [KMAX][LDR]
     double* vbuf;   // [32]
     double* zbuf;   // [32]
@@ -100,7 +112,7 @@ struct GiScratch {
     int*    Wi;     // [32]  variable of slot a
 };
 
-template <int KMAX, int TCS, int LDR, class ColumnFn>
+template <int KMAX, int LDR, class ColumnFn>
 __device__ __forceinline__ void gi_active_set(const GiScratch& w, int i, int half, bool var, double lo, double hi,
                                               double tol, int max_iter, double& nu, int& st_code, int& it,
                                               bool& in_w, double& my_sig, ColumnFn&& column_of_P) {
@@ -109,6 +121,12 @@ __device__ __forceinline__ void gi_active_set(const GiScratch& w, int i, int hal
     bool s_live = false;
     int s_var = 0;
     double s_sg = 0.0, s_mu = 0.0;
+    // columns sigma_a P e_{w_a} of the active bounds: entry i of slot a's column lives in lane i's
+    // register tc[a] (static indices only: slot loops are unrolled over KMAX and dead slots carry a
+    // zero dual step, so no predicate and no LDS image is needed)
+    double tc[KMAX];
+#pragma unroll
+    for (int a = 0; a < KMAX; ++a) tc[a] = 0.0;
     int nW = 0, hiW = 0;
     if (i < KMAX) {
         for (int b = 0; b < KMAX; ++b) w.Rinv[i * LDR + b] = 0.0;
@@ -149,8 +167,8 @@ __device__ __forceinline__ void gi_active_set(const GiScratch& w, int i, int hal
             wcqp::wave_lds_fence();
             // primal step z = tp - sum_a r_a Tc[a]
             double z = tp;
-#pragma unroll 1
-            for (int a = 0; a < hiW; ++a) z = fma(-w.rvec[a], w.Tc[a * TCS + (var ? i : 0)], z);
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a) z = fma(-w.rvec[a], tc[a], z);
             w.zbuf[i] = z;
             wcqp::wave_lds_fence();
             const double nzv = sig * w.zbuf[p];          // Schur complement of the bordered system
@@ -182,7 +200,8 @@ __device__ __forceinline__ void gi_active_set(const GiScratch& w, int i, int hal
                     s_live = true; s_var = p; s_sg = sig; s_mu = mu_p;
                     w.Wi[n] = p;
                 }
-                if (var) w.Tc[n * TCS + i] = tp;
+#pragma unroll
+                for (int a = 0; a < KMAX; ++a) tc[a] = (a == n) ? tp : tc[a];
                 if (i == p) { in_w = true; my_sig = sig; }
                 ++nW;
                 hiW = hiW > n + 1 ? hiW : n + 1;
