@@ -110,6 +110,10 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 
     WCQP_STAMP(0);
     // ---------------- phase 0: loads (column i of every task Jacobian) -------------------
+    // per-variable constants first: their L2 latency hides under the Jacobian loads instead of
+    // being exposed where they are consumed
+    double Di = prm->lam[i], kq_i = prm->kq[i], qreg_i = prm->qreg[i];
+    double lo = var ? prm->vlo[i] : -inf, hi = var ? prm->vhi[i] : inf;
     double a[MEQ];          // column i of A = [J_left; J_right; (J_com)]; on lane 29: b
     double cn[NCOST];       // column i of the cost rows [ (J_com;) J_neck ]
     {
@@ -162,7 +166,6 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         bvec[i] = b_mine;
     }
     double g = 0.0;             // gradient entry of this variable (osqp.cpp:181-196, qp.cpp:161-178)
-    const double Di = prm->lam[i];
     {
         const double kap = prm->kappa * (-prm->k_neck);
         const double e0 = kap * rot_err(st + 48, st + 57, 0);
@@ -174,7 +177,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         constexpr int NO = NCOST - 3;                      // neck rows offset inside cn
         if (var) {
             g = -(cn[NO] * y0 + cn[NO + 1] * y1 + cn[NO + 2] * y2);
-            if (i >= 6) g -= prm->kq[i] * (prm->qreg[i] - st[kStateLen + i - 6]);
+            if (i >= 6) g -= kq_i * (qreg_i - st[kStateLen + i - 6]);
             if constexpr (!USE_COM) {
                 const double w0 = prm->Wc[0] * st[72] + prm->Wc[1] * st[73] + prm->Wc[2] * st[74];
                 const double w1 = prm->Wc[3] * st[72] + prm->Wc[4] * st[73] + prm->Wc[5] * st[74];
@@ -414,7 +417,6 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     int it = 0;
     bool in_w = false;
     double my_sig = 0.0;
-    const double lo = var ? prm->vlo[i] : -inf, hi = var ? prm->vhi[i] : inf;
     const double tol = prm->tol;
     const bool need = !osqp_form && var && i >= 6 && fmax(nu - hi, lo - nu) > tol;
     if (__ballot(need) != 0ull) {
