@@ -65,12 +65,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the solve path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)          # == local_rank on a full node; lets a 1-GPU box rehearse N > 1
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
+    backend = os.environ.get("WCQP_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     B = args.batch
@@ -166,10 +172,7 @@ def main():
         step(events[k])
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, torch, dev, elapsed)
     ik_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))      # IK kernel, HIP events on its stream
     # MPC kernel duration: a short separately timed run (it is not the dominant kernel)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -231,6 +234,15 @@ def main():
         dist.destroy_process_group()
 
 
+def max_over_ranks(dist, torch, dev, value):
+    if dist is None:
+        return value
+    on = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     """BASELINE configs[3]/[4]: every step is one robot-tick of the whole batch — MPC on the
     receding window of the per-instance DCM trajectory, ZMP-CoM glue, IK, joint integration —
@@ -259,10 +271,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     e1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, torch, dev, elapsed)
     out_state = pipe.download()
     dev_ms = e0.elapsed_time(e1) / args.steps
     value = 2 * B * world * args.steps / elapsed

@@ -206,16 +206,17 @@ int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
  * Device-resident tick pipeline — BASELINE configs 4/5 and SURVEY.md §8f-1/2: the call
  * order of WalkingModule::updateModule around the two solvers (WM/src/WalkingModule.cpp:
  * 578-745) for a batch of synthetic robots, kept entirely on the GPU:
- *   pre   contact pair of this tick, hull rows swapped on change (= setConvexHullConstraint,
- *         cold start of that instance), LIPM reference (StableDCMModel.cpp:63-90)
- *   MPC   window [t, t+N] of the per-instance DCM reference trajectory (the deque that
+ *   MPC   hull rows of this tick's contact pair (= setConvexHullConstraint; the kernel indexes one
+ *         of the three precomputed row sets, so a contact change costs nothing),
+ *         window [t, t+N] of the per-instance DCM reference trajectory (the deque that
  *         advances one stage per tick, WalkingModule.cpp:35-96), x0 = measured DCM,
  *         u_prev = previous output (MPCSolver.cpp:244-245)
- *   glue  ZMP-CoM law + integrator (WalkingZMPController.cpp:146-173) -> desired CoM position /
+ *   glue  LIPM reference (StableDCMModel.cpp:63-90), ZMP-CoM law + integrator
+ *         (WalkingZMPController.cpp:146-173) -> desired CoM position /
  *         velocity into the IK pose block (WalkingModule.cpp:686-695); synthetic LIPM plant
  *   IK    joint velocities
- *   post  q <- Integrator(dq) (WalkingModule.cpp:741-744)
- * The six launches of a tick are captured ONCE in a hipGraph and replayed per tick
+ *   post  q <- Integrator(dq) (WalkingModule.cpp:741-744), contact pair of the next tick, tick += 1
+ * The four launches of a tick are captured ONCE in a hipGraph and replayed per tick
  * (`use_graph`), with the tick index living in device memory.
  * ===================================================================================== */
 typedef struct wcqp_tick_params {

@@ -96,6 +96,33 @@ def test_mpc_edge_cases(wca, qs):
     assert np.array_equal(one["u0"][0], full["u0"][0])
 
 
+def test_mpc_shipped_horizon_200(wca, qs):
+    """The shipped configuration: controllerHorizon 2 s at 10 ms -> N = 200, n = 802
+    (CFG/controllerParams.ini:1); the kernel loops over 64-stage passes."""
+    N = 200
+    c = qs.mpc_constants(qs.MPCParams(horizon=N))
+    b = wca.synth.synth_mpc_batch(20, seed=41, horizon=N, uprev_sigma=0.04)
+    out = wca.MpcSolver(horizon=N).solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    for i in range(20):
+        r = qs.mpc_exact(c, b["x0"][i], b["ref"][i], b["u_prev"][i], b["hull_A"][i], b["hull_b"][i], int(b["hull_nc"][i]))
+        assert out["status"][i] == 0 and np.abs(out["u0"][i] - r["u0"]).max() <= SOL_TOL
+        if r["mu_min_active"] > MARGIN and r["slack_min_inactive"] > MARGIN:
+            assert int(out["active"][i]) == sum(1 << e for e in r["active"])
+
+
+def test_mpc_coupled_weights(wca, qs):
+    """Non-diagonal (but symmetric) Q and R couple the two axes: Sigma0 is a full 2x2 metric."""
+    Q = np.array([[7000.0, 1500.0], [1500.0, 5000.0]]); R = np.array([[9e6, -2e6], [-2e6, 6e6]])
+    c = qs.mpc_constants(qs.MPCParams(Q=Q, R=R))
+    b = wca.synth.synth_mpc_batch(48, seed=43, uprev_sigma=0.05)
+    out = wca.MpcSolver(Q=Q, R=R).solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    for i in range(48):
+        r = qs.mpc_exact(c, b["x0"][i], b["ref"][i], b["u_prev"][i], b["hull_A"][i], b["hull_b"][i], int(b["hull_nc"][i]))
+        assert np.abs(out["u0"][i] - r["u0"]).max() <= SOL_TOL
+        if r["mu_min_active"] > MARGIN and r["slack_min_inactive"] > MARGIN:
+            assert int(out["active"][i]) == sum(1 << e for e in r["active"])
+
+
 def test_mpc_properties_at_full_size(wca):
     """BASELINE config 4 per-GPU size (8192): feasibility, idempotence, permutation invariance."""
     B = 8192

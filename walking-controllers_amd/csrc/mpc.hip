@@ -58,7 +58,7 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
                           int ref_stride, const int* __restrict__ ref_start,
                           const double* __restrict__ u_prev,
                           const double* __restrict__ hull_A, const double* __restrict__ hull_b,
-                          const int* __restrict__ hull_nc,
+                          const int* __restrict__ hull_nc, int hull_sets, const int* __restrict__ hull_sel,
                           double* __restrict__ u0_out, int* __restrict__ status_out,
                           unsigned* __restrict__ active_out, double* __restrict__ margin_out)
 {
@@ -104,12 +104,15 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
         uy += c.Gx[2] * xs.x + c.Gx[3] * xs.y + c.Gu[2] * up.x + c.Gu[3] * up.y;
     }
     // hull rows -> LDS (lanes 0..7 of the instance own one row each)
-    int nc = hull_nc[inst];
+    // an instance may carry several precomputed row sets (one per contact pair); `hull_sel` picks
+    // the live one, so a contact change costs no copy (tick pipeline)
+    const long hset = inst * hull_sets + (hull_sel ? hull_sel[inst] : 0);
+    int nc = hull_nc[hset];
     nc = nc < 0 ? 0 : (nc > WCQP_HULL_ROWS ? WCQP_HULL_ROWS : nc);
     double rax = 0.0, ray = 0.0, rb = 0.0, rn = 0.0;    // this lane's own hull row (lanes 0..7)
     if (t < WCQP_HULL_ROWS) {
-        const double2 a = reinterpret_cast<const double2*>(hull_A)[inst * WCQP_HULL_ROWS + t];
-        rb = hull_b[inst * WCQP_HULL_ROWS + t];
+        const double2 a = reinterpret_cast<const double2*>(hull_A)[hset * WCQP_HULL_ROWS + t];
+        rb = hull_b[hset * WCQP_HULL_ROWS + t];
         rax = a.x; ray = a.y; rn = sqrt(a.x * a.x + a.y * a.y);
         s_hull[sub][t][0] = rax; s_hull[sub][t][1] = ray; s_hull[sub][t][2] = rb; s_hull[sub][t][3] = rn;
     }
@@ -327,9 +330,9 @@ namespace wcqp {
 
 int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, int ref_len, int ref_stride,
                 const int* ref_start_dev, const double* u_prev,
-                const double* hull_A, const double* hull_b, const int* hull_nc,
+                const double* hull_A, const double* hull_b, const int* hull_nc, int hull_sets, const int* hull_sel,
                 double* u0, int* status, unsigned* active, double* margin, hipStream_t stream) {
-    if (!h || batch < 0 || ref_len < 1 || ref_stride < ref_len) return WCQP_E_INVALID;
+    if (!h || batch < 0 || ref_len < 1 || ref_stride < ref_len || hull_sets < 1) return WCQP_E_INVALID;
     if (!x0 || !ref || !u_prev || !hull_A || !hull_b || !hull_nc || !u0 || !status) return WCQP_E_INVALID;
     if (batch == 0) return WCQP_OK;
     const int rc = ensure_device(h);
@@ -344,7 +347,7 @@ int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, in
     c.N = h->N;
     const unsigned grid = (unsigned)((batch + kInstPerWave - 1) / kInstPerWave);
     hipLaunchKernelGGL(mpc_condensed_kernel, dim3(grid), dim3(kBlock), 0, stream,
-                       c, batch, x0, ref, ref_len, ref_stride, ref_start_dev, u_prev, hull_A, hull_b, hull_nc,
+                       c, batch, x0, ref, ref_len, ref_stride, ref_start_dev, u_prev, hull_A, hull_b, hull_nc, hull_sets, hull_sel,
                        u0, status, active, margin);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
@@ -406,7 +409,7 @@ int wcqp_mpc_solve_device(wcqp_mpc_t h, int32_t batch,
                           const double* x0, const double* ref, int32_t ref_len, const double* u_prev,
                           const double* hull_A, const double* hull_b, const int32_t* hull_nc,
                           double* u0, int32_t* status, uint32_t* active, double* margin, void* stream) {
-    return wcqp::mpc_enqueue(h, batch, x0, ref, ref_len, ref_len, nullptr, u_prev, hull_A, hull_b, hull_nc,
+    return wcqp::mpc_enqueue(h, batch, x0, ref, ref_len, ref_len, nullptr, u_prev, hull_A, hull_b, hull_nc, 1, nullptr,
                              u0, status, active, margin, (hipStream_t)stream);
 }
 

@@ -3,7 +3,7 @@
 // CPU restatement every number is checked against.
 //
 // Reference call order reproduced (citations relative to /root/reference/modules/Walking_module):
-//   src/WalkingModule.cpp:578-597   StableDCMModel::integrateModel        -> tick_pre_kernel
+//   src/WalkingModule.cpp:578-597   StableDCMModel::integrateModel        -> tick_glue_kernel (consumer)
 //   src/WalkingModule.cpp:604-636   MPC bracket                           -> mpc_condensed_kernel
 //   src/WalkingModule.cpp:657-695   WalkingZMPController + desired CoM    -> tick_glue_kernel
 //   src/WalkingModule.cpp:709-740   IK bracket                            -> ik_kernel
@@ -25,10 +25,11 @@ struct TickDev {
     const int* phase0; const double* swing_twist;
     // per-instance state
     double *dcm, *com, *zmp_meas, *u_prev, *u0, *c_ref, *v_ref, *p_star, *v_star_prev, *v_ref_prev;
-    double *q_des, *dq_prev, *dq, *hull_A, *hull_b, *state;
-    int *hull_nc, *code_prev, *mpc_status, *ik_status;
+    double *q_des, *dq_prev, *dq, *state;
+    int *sel, *mpc_status, *ik_status;     // sel: contact pair of the CURRENT tick (0 left, 1 right, 2 both)
     long long *mpc_fail, *ik_fail;
-    int* tick;
+    int* tick;          // ticks completed; read by the MPC window and the glue
+    int* tick_latched;  // copy made by the glue for the post kernel, which then advances `tick`
     double *u0_log, *dq_log;
     // scalars
     int batch, first, traj_len, log_ticks, step_ticks, ds_ticks;
@@ -55,23 +56,15 @@ __device__ __forceinline__ int contact_code(int t, int phase0, int step_ticks, i
     return s < ds_ticks ? 2 : side;                 // 0 = left only, 1 = right only, 2 = both
 }
 
-__global__ void tick_pre_kernel(TickDev d) {
+__global__ void tick_glue_kernel(TickDev d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.batch) return;
     const int t = *d.tick;
-    const int code = contact_code(t, d.phase0[i], d.step_ticks, d.ds_ticks);
-    if (code != d.code_prev[i]) {
-        // WalkingController::setConvexHullConstraint: rows change only when the contact pair does
-        // (…PredictiveController.cpp:369-374); the reference then builds a new MPCSolver (cold start)
-        for (int k = 0; k < WCQP_HULL_ROWS; ++k) {
-            d.hull_A[(size_t)i * 16 + 2 * k] = d.hull_tab_A[((size_t)i * 3 + code) * 16 + 2 * k];
-            d.hull_A[(size_t)i * 16 + 2 * k + 1] = d.hull_tab_A[((size_t)i * 3 + code) * 16 + 2 * k + 1];
-            d.hull_b[(size_t)i * 8 + k] = d.hull_tab_b[((size_t)i * 3 + code) * 8 + k];
-        }
-        d.hull_nc[i] = d.hull_tab_nc[(size_t)i * 3 + code];
-        d.code_prev[i] = code;
-    }
-    // StableDCMModel::integrateModel (StableDCMModel.cpp:63-90), Tustin integrator
+    if (i == 0) *d.tick_latched = t;
+    const int code = d.sel[i];
+    const int st = d.mpc_status[i];
+    // StableDCMModel::integrateModel (StableDCMModel.cpp:63-90), Tustin integrator; it precedes the
+    // MPC in the reference (WalkingModule.cpp:578-597) but only the ZMP-CoM law below consumes it
     for (int ax = 0; ax < 2; ++ax) {
         const double r = d.ref_traj[((size_t)i * d.traj_len + t) * 2 + ax];
         const double v = -d.omega * (d.c_ref[2 * i + ax] - r);
@@ -79,14 +72,6 @@ __global__ void tick_pre_kernel(TickDev d) {
         d.v_ref_prev[2 * i + ax] = v;
         d.v_ref[2 * i + ax] = v;
     }
-}
-
-__global__ void tick_glue_kernel(TickDev d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.batch) return;
-    const int t = *d.tick;
-    const int code = d.code_prev[i];
-    const int st = d.mpc_status[i];
     const bool ok = st == WCQP_STATUS_SOLVED || st == WCQP_STATUS_OUTSIDE_HULL;
     if (!ok) d.mpc_fail[i] += 1;
     double* s = d.state + (size_t)i * kStateLen;
@@ -120,16 +105,21 @@ __global__ void tick_post_kernel(TickDev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.batch * kDof) return;
     const int i = g / kDof;
-    const int t = *d.tick;
+    const int t = *d.tick_latched;
     const bool ok = d.ik_status[i] == WCQP_STATUS_SOLVED;
     const double v = ok ? d.dq[g] : 0.0;
     if (!ok && g % kDof == 0) d.ik_fail[i] += 1;
     d.q_des[g] += 0.5 * d.dT * (v + d.dq_prev[g]);             // WalkingModule.cpp:741-744
     d.dq_prev[g] = v;
     if (t < d.log_ticks) d.dq_log[(size_t)t * d.batch * kDof + g] = v;
+    if (g % kDof == 0) {
+        // contact pair of the NEXT tick: WalkingController::setConvexHullConstraint switches rows only
+        // when the pair changes (…PredictiveController.cpp:369-374) — here the MPC kernel simply
+        // reads the row set this index selects
+        d.sel[i] = contact_code(t + 1, d.phase0[i], d.step_ticks, d.ds_ticks);
+    }
+    if (g == 0) *d.tick = t + 1;      // advanceReferenceSignals (WalkingModule.cpp:816); nobody reads `tick` any more this tick
 }
-
-__global__ void tick_advance_kernel(int* tick) { *tick += 1; }   // advanceReferenceSignals (WalkingModule.cpp:816)
 
 }  // namespace
 
@@ -164,16 +154,15 @@ int enqueue_tick(wcqp_tick_s* h, hipStream_t s) {
     const TickDev& d = h->d;
     const int B = d.batch;
     const int N = wcqp::mpc_horizon(h->mpc);
-    hipLaunchKernelGGL(tick_pre_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d);
     int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick, d.u_prev,
-                               d.hull_A, d.hull_b, d.hull_nc, d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
+                               d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, 3, d.sel,
+                               d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
     if (rc != WCQP_OK) return rc;
     hipLaunchKernelGGL(tick_glue_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d);
     rc = wcqp_ik_solve_device(h->ik, B, h->J_left, h->J_right, h->J_neck, h->J_com, d.q_des, d.state,
                               d.dq, d.ik_status, h->ik_lo, h->ik_up, nullptr, nullptr, s);
     if (rc != WCQP_OK) return rc;
     hipLaunchKernelGGL(tick_post_kernel, dim3((B * kDof + 255) / 256), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(tick_advance_kernel, dim3(1), dim3(1), 0, s, d.tick);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }
@@ -217,7 +206,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     A_(d.dcm, B * 2); A_(d.com, B * 2); A_(d.zmp_meas, B * 2); A_(d.u_prev, B * 2); A_(d.u0, B * 2);
     A_(d.c_ref, B * 2); A_(d.v_ref, B * 2); A_(d.v_ref_prev, B * 2); A_(d.p_star, B * 2); A_(d.v_star_prev, B * 2);
     A_(d.q_des, B * kDof); A_(d.dq_prev, B * kDof); A_(d.dq, B * kDof);
-    A_(d.hull_A, B * 16); A_(d.hull_b, B * 8); A_(d.hull_nc, B); A_(d.code_prev, B);
+    A_(d.sel, B); A_(d.tick_latched, 1);
     A_(d.state, B * kStateLen); A_(d.mpc_status, B); A_(d.ik_status, B); A_(d.mpc_fail, B); A_(d.ik_fail, B);
     A_(d.tick, 1); A_(d.u0_log, (size_t)d.log_ticks * B * 2); A_(d.dq_log, (size_t)d.log_ticks * B * kDof);
     A_(h->J_left, B * 6 * 29); A_(h->J_right, B * 6 * 29); A_(h->J_neck, B * 3 * 29); A_(h->J_com, B * 3 * 29);
@@ -260,7 +249,14 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
 #undef UP_
     WCQP_HIP_TRY(hipMemset(d.v_ref_prev, 0, B * 16)); WCQP_HIP_TRY(hipMemset(d.v_star_prev, 0, B * 16));
     WCQP_HIP_TRY(hipMemset(d.dq_prev, 0, B * kDof * 8)); WCQP_HIP_TRY(hipMemset(d.tick, 0, 4));
-    WCQP_HIP_TRY(hipMemset(d.code_prev, 0xFF, B * 4));           // -1: the first tick always loads its hull
+    {   // contact pair of tick 0 (later ticks: tick_post_kernel)
+        std::vector<int> sel(B);
+        for (size_t i = 0; i < B; ++i) {
+            const int cyc = in->phase0[i] % (2 * d.step_ticks), sidx = cyc % d.step_ticks;
+            sel[i] = sidx < d.ds_ticks ? 2 : cyc / d.step_ticks;
+        }
+        WCQP_HIP_TRY(hipMemcpy(d.sel, sel.data(), B * 4, hipMemcpyHostToDevice));
+    }
     WCQP_HIP_TRY(hipMemset(d.mpc_fail, 0, B * 8)); WCQP_HIP_TRY(hipMemset(d.ik_fail, 0, B * 8));
     h->uploaded = true;
     return WCQP_OK;
@@ -274,7 +270,7 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         return WCQP_OK;
     }
     if (!h->graph_exec) {
-        // one tick = six launches, captured once; the tick index lives in HBM so the graph is tick-invariant
+        // one tick = four launches, captured once; the tick index lives in HBM so the graph is tick-invariant
         hipStream_t cs = nullptr;
         WCQP_HIP_TRY(hipStreamCreate(&cs));
         // a first plain tick would advance the state, so make sure lazy device state of the solver
