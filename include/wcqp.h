@@ -122,6 +122,27 @@ int wcqp_mpc_solve_host(wcqp_mpc_t h, int32_t batch,
                         double* u0, int32_t* status, uint32_t* active, double* margin);
 
 /* =====================================================================================
+ * Support polygon rows from foot poses — the batch analogue of
+ * WalkingController::setConvexHullConstraint -> buildConvexHull
+ * (WM/src/WalkingDCMModelPredictiveController.cpp:364-489): feet rectangles
+ * (foot_size, cpp:295-303) transformed by the foot poses, projected on the XY plane, 2-D
+ * convex hull.  iDynTree's row order / normalisation is upstream and unpinned, so the
+ * convention is this library's own: CCW hull, unit outward normals,
+ * rows a.u <= b, padded to 8 rows with 0.u <= 1e30.
+ *   foot_rect[8]            corners (x, y) x 4 of the foot rectangle in the foot frame
+ *   left_T / right_T[B][12] foot-to-world transforms: position (3) + row-major rotation (9)
+ *   contact[B]              bit 0 = left foot in contact, bit 1 = right foot in contact
+ * outputs hull_A[B][8][2], hull_b[B][8], hull_nc[B] (0 when no foot is in contact — the
+ * reference refuses that case, cpp:406-410; the MPC kernel then reports the unconstrained u0).
+ * ===================================================================================== */
+int wcqp_hull_from_feet_device(int32_t batch, const double* foot_rect,
+                               const double* left_T, const double* right_T, const uint8_t* contact,
+                               double* hull_A, double* hull_b, int32_t* hull_nc, void* stream);
+int wcqp_hull_from_feet_host(int32_t batch, const double* foot_rect,
+                             const double* left_T, const double* right_T, const uint8_t* contact,
+                             double* hull_A, double* hull_b, int32_t* hull_nc);
+
+/* =====================================================================================
  * QP-IK — replaces WalkingQPIK_osqp::solve / WalkingQPIK_qpOASES::solve and the
  *         OsqpEigen::Solver / qpOASES::SQProblem objects behind them
  *         (WM/src/WalkingQPInverseKinematics_osqp.cpp:340-428,

@@ -181,3 +181,15 @@ def test_c_ik_restatement(qs, wca, form, vmax):
         assert np.abs(dq[i] - r["dq"]).max() < tol
         if form == "qpoases":
             assert int(lo[i]) == sum(1 << j for j in r["lower"]) and int(up[i]) == sum(1 << j for j in r["upper"])
+
+
+def test_c_oracle_is_clean_under_asan_ubsan():
+    """Sanitizers run on the CPU build only (GPU ASan is not available on this pool): the C
+    restatement that parity and the CPU baseline rest on must itself be memory- and UB-clean."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "asan"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1", OMP_NUM_THREADS="2")
+    r = subprocess.run([os.path.join(root, "oracle", "_build", "selftest_asan")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "mpc fail 0" in r.stdout and "ik form 0 fail 0" in r.stdout and "ik form 1 fail 0" in r.stdout, r.stdout

@@ -142,6 +142,39 @@ def test_mpc_properties_at_full_size(wca):
     assert np.array_equal(out2["active"], act[perm])
 
 
+def test_hull_rows_from_foot_poses(wca, qs):
+    """§8f-3: device hull builder against the numpy builder of the synthetic workloads and the
+    C++ host mirror's convention; then straight into the MPC kernel."""
+    rng = np.random.default_rng(7)
+    B = 300
+    rect = np.array([0.05, 0.025, 0.05, -0.025, -0.02, -0.025, -0.02, 0.025])     # foot_size corners
+    def pose(xy, yaw):
+        T = np.zeros((B, 12)); T[:, 0:2] = xy; c, s = np.cos(yaw), np.sin(yaw)
+        T[:, 3] = c; T[:, 4] = -s; T[:, 6] = s; T[:, 7] = c; T[:, 11] = 1.0
+        return T
+    lxy = rng.normal(0, 0.02, (B, 2)) + [0.0, 0.08]; rxy = rng.normal(0, 0.03, (B, 2)) + [0.03, -0.08]
+    lyaw, ryaw = rng.uniform(-0.4, 0.4, B), rng.uniform(-0.4, 0.4, B)
+    contact = rng.integers(0, 4, B).astype(np.uint8)
+    A, b, nc = wca.hull_from_feet_host(rect, pose(lxy, lyaw), pose(rxy, ryaw), contact)
+    for i in range(B):
+        pts = []
+        if contact[i] & 1: pts.append(wca.synth.foot_corners(lxy[i], lyaw[i]))
+        if contact[i] & 2: pts.append(wca.synth.foot_corners(rxy[i], ryaw[i]))
+        if not pts:
+            assert nc[i] == 0
+            continue
+        Ar, br, ncr = wca.synth.hull_rows(np.vstack(pts))
+        assert nc[i] == ncr
+        assert np.abs(A[i] - Ar).max() < 1e-12 and np.abs(b[i, :ncr] - br[:ncr]).max() < 1e-12 and (b[i, ncr:] == 1e30).all()
+    # rows feed the MPC kernel unchanged
+    m = wca.synth.synth_mpc_batch(B, seed=3, uprev_sigma=0.05)
+    out = wca.MpcSolver().solve_host(m["x0"], m["ref"], m["u_prev"], A, b, nc)
+    c = qs.mpc_constants(qs.MPCParams())
+    for i in range(0, B, 7):
+        r = qs.mpc_exact(c, m["x0"][i], m["ref"][i], m["u_prev"][i], A[i], b[i], int(nc[i]))
+        assert np.abs(out["u0"][i] - r["u0"]).max() <= SOL_TOL
+
+
 # -------------------------------------------------------------------------------- IK ---
 def _ik_solver(wca, form, vmax, algorithm=0):
     return wca.IkSolver(form=wca.IK_FORM_QPOASES if form == "qpoases" else wca.IK_FORM_OSQP, v_max=vmax,

@@ -1,6 +1,7 @@
+#!/bin/bash
+# GPU suite incl. the device hull builder test
+set -o pipefail
 mkdir -p gpurun_out
-L=$PWD/walking-controllers_amd/csrc/build/diag/libwcqp_stamps.so
-WCQP_LIB_PATH=$L timeout -k 10 100 python tools/stamps.py 4096 0.5 > gpurun_out/stamps.log 2>&1
-WCQP_LIB_PATH=$L timeout -k 10 100 python tools/stamps.py 65536 0.5 >> gpurun_out/stamps.log 2>&1
-WCQP_LIB_PATH=$L timeout -k 10 100 python tools/stamps.py 64 100 >> gpurun_out/stamps.log 2>&1
-grep median gpurun_out/stamps.log
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/run15_tests.log 2>&1
+echo "tests exit $?" >> gpurun_out/run15_tests.log
+tail -5 gpurun_out/run15_tests.log

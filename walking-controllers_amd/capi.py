@@ -31,6 +31,7 @@ ABI_SYMBOLS = (
     "wcqp_mpc_create", "wcqp_mpc_destroy", "wcqp_mpc_get_condensed", "wcqp_mpc_get_matrices",
     "wcqp_mpc_solve_device", "wcqp_mpc_solve_host",
     "wcqp_ik_create", "wcqp_ik_destroy", "wcqp_ik_solve_device", "wcqp_ik_solve_host",
+    "wcqp_hull_from_feet_device", "wcqp_hull_from_feet_host",
     "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download",
 )
 
@@ -99,6 +100,8 @@ def lib() -> C.CDLL:
         ik_args = [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp, dp, ip, up, up, dp, ip]
         L.wcqp_ik_solve_device.argtypes = ik_args + [vp]
         L.wcqp_ik_solve_host.argtypes = ik_args
+        L.wcqp_hull_from_feet_device.argtypes = [C.c_int32] + [C.c_void_p] * 8
+        L.wcqp_hull_from_feet_host.argtypes = [C.c_int32] + [C.c_void_p] * 7
         L.wcqp_tick_create.argtypes = [C.POINTER(TickParams), C.POINTER(C.c_void_p)]
         L.wcqp_tick_destroy.argtypes = [C.c_void_p]
         L.wcqp_tick_upload.argtypes = [C.c_void_p, C.POINTER(TickInputs)]
@@ -239,6 +242,17 @@ class IkSolver:
                                          active_lower or None, active_upper or None, foot_err or None,
                                          iters or None, stream or None),
               "wcqp_ik_solve_device")
+
+
+def hull_from_feet_host(foot_rect, left_T, right_T, contact):
+    """Batch analogue of WalkingController::setConvexHullConstraint: foot poses -> hull rows."""
+    foot_rect, left_T, right_T = _f64(foot_rect).reshape(8), _f64(left_T), _f64(right_T)
+    contact = np.ascontiguousarray(contact, dtype=np.uint8)
+    B = contact.shape[0]
+    A = np.zeros((B, HULL_ROWS, 2)); b = np.zeros((B, HULL_ROWS)); nc = np.zeros(B, np.int32)
+    check(lib().wcqp_hull_from_feet_host(B, _p(foot_rect), _p(left_T), _p(right_T), _p(contact), _p(A), _p(b), _p(nc)),
+          "wcqp_hull_from_feet_host")
+    return A, b, nc
 
 
 class TickPipeline:

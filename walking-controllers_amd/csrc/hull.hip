@@ -1,0 +1,112 @@
+// Support-polygon rows from foot poses.  One thread per robot instance: the
+// hull of at most 8 points is a few dozen flops, the kernel is a pure streaming pass
+// (2 x 96 B in, 200 B out per instance).
+//
+// Reference: WalkingController::setConvexHullConstraint / buildConvexHull
+//            src/WalkingDCMModelPredictiveController.cpp:364-489 (iDynTree ConvexHullHelpers upstream).
+#include <cmath>
+#include "wcqp_internal.h"
+
+namespace {
+
+__global__ void hull_from_feet_kernel(int batch, const double* __restrict__ rect,
+                                      const double* __restrict__ left_T, const double* __restrict__ right_T,
+                                      const unsigned char* __restrict__ contact,
+                                      double* __restrict__ hull_A, double* __restrict__ hull_b, int* __restrict__ hull_nc) {
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= batch) return;
+    double px[8], py[8];
+    int np = 0;
+    const unsigned c = contact[inst];
+    for (int f = 0; f < 2; ++f) {
+        if (!((c >> f) & 1u)) continue;
+        const double* T = (f == 0 ? left_T : right_T) + (size_t)inst * 12;
+        for (int k = 0; k < 4; ++k) {
+            const double x = rect[2 * k], y = rect[2 * k + 1];
+            // foot-frame corner (x, y, 0) -> world, projected on the XY plane through the origin
+            px[np] = T[3] * x + T[4] * y + T[0];
+            py[np] = T[6] * x + T[7] * y + T[1];
+            ++np;
+        }
+    }
+    double* A = hull_A + (size_t)inst * 16;
+    double* b = hull_b + (size_t)inst * 8;
+    for (int k = 0; k < 8; ++k) { A[2 * k] = 0.0; A[2 * k + 1] = 0.0; b[k] = 1e30; }
+    if (np < 3) { hull_nc[inst] = 0; return; }
+    // insertion sort by (x, y), then Andrew's monotone chain (collinear points dropped)
+    for (int i = 1; i < np; ++i) {
+        const double x = px[i], y = py[i];
+        int j = i - 1;
+        while (j >= 0 && (px[j] > x || (px[j] == x && py[j] > y))) { px[j + 1] = px[j]; py[j + 1] = py[j]; --j; }
+        px[j + 1] = x; py[j + 1] = y;
+    }
+    double hx[16], hy[16];
+    int k = 0;
+    for (int i = 0; i < np; ++i) {                                  // lower hull
+        while (k >= 2 && (hx[k - 1] - hx[k - 2]) * (py[i] - hy[k - 2]) - (hy[k - 1] - hy[k - 2]) * (px[i] - hx[k - 2]) <= 0) --k;
+        hx[k] = px[i]; hy[k] = py[i]; ++k;
+    }
+    const int lower = k + 1;
+    for (int i = np - 2; i >= 0; --i) {                             // upper hull
+        while (k >= lower && (hx[k - 1] - hx[k - 2]) * (py[i] - hy[k - 2]) - (hy[k - 1] - hy[k - 2]) * (px[i] - hx[k - 2]) <= 0) --k;
+        hx[k] = px[i]; hy[k] = py[i]; ++k;
+    }
+    const int nc = k - 1;                                           // last point == first point
+    for (int e = 0; e < nc; ++e) {
+        const double dx = hx[e + 1] - hx[e], dy = hy[e + 1] - hy[e];
+        const double len = sqrt(dx * dx + dy * dy);
+        const double ax = dy / len, ay = -dx / len;                 // outward normal of a CCW edge
+        A[2 * e] = ax; A[2 * e + 1] = ay;
+        b[e] = ax * hx[e] + ay * hy[e];
+    }
+    hull_nc[inst] = nc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wcqp_hull_from_feet_device(int32_t batch, const double* foot_rect, const double* left_T, const double* right_T,
+                               const uint8_t* contact, double* hull_A, double* hull_b, int32_t* hull_nc, void* stream) {
+    if (batch < 0 || !foot_rect || !left_T || !right_T || !contact || !hull_A || !hull_b || !hull_nc) return WCQP_E_INVALID;
+    if (batch == 0) return WCQP_OK;
+    hipLaunchKernelGGL(hull_from_feet_kernel, dim3((batch + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       batch, foot_rect, left_T, right_T, contact, hull_A, hull_b, hull_nc);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+int wcqp_hull_from_feet_host(int32_t batch, const double* foot_rect, const double* left_T, const double* right_T,
+                             const uint8_t* contact, double* hull_A, double* hull_b, int32_t* hull_nc) {
+    if (batch < 0 || !foot_rect || !left_T || !right_T || !contact || !hull_A || !hull_b || !hull_nc) return WCQP_E_INVALID;
+    if (batch == 0) return WCQP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        std::fprintf(stderr, "[wcqp] no HIP device: the hull builder has no CPU fallback\n");
+        return WCQP_E_HIP;
+    }
+    const size_t B = (size_t)batch;
+    double *d_rect = nullptr, *d_l = nullptr, *d_r = nullptr, *d_A = nullptr, *d_b = nullptr;
+    unsigned char* d_c = nullptr; int* d_n = nullptr;
+    int rc = WCQP_OK;
+    if (hipMalloc(&d_rect, 64) != hipSuccess || hipMalloc(&d_l, B * 96) != hipSuccess || hipMalloc(&d_r, B * 96) != hipSuccess ||
+        hipMalloc(&d_A, B * 128) != hipSuccess || hipMalloc(&d_b, B * 64) != hipSuccess || hipMalloc(&d_c, B) != hipSuccess ||
+        hipMalloc(&d_n, B * 4) != hipSuccess) rc = WCQP_E_NOMEM;
+    if (rc == WCQP_OK) {
+        (void)hipMemcpy(d_rect, foot_rect, 64, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_l, left_T, B * 96, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_r, right_T, B * 96, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_c, contact, B, hipMemcpyHostToDevice);
+        rc = wcqp_hull_from_feet_device(batch, d_rect, d_l, d_r, d_c, d_A, d_b, d_n, nullptr);
+        if (rc == WCQP_OK && hipDeviceSynchronize() != hipSuccess) rc = WCQP_E_HIP;
+        if (rc == WCQP_OK) {
+            (void)hipMemcpy(hull_A, d_A, B * 128, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hull_b, d_b, B * 64, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hull_nc, d_n, B * 4, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d_rect); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_A); (void)hipFree(d_b); (void)hipFree(d_c); (void)hipFree(d_n);
+    return rc;
+}
+
+}  // extern "C"
