@@ -181,7 +181,7 @@ def _ik_solver(wca, form, vmax, algorithm=0):
                         algorithm=algorithm)
 
 
-@pytest.mark.parametrize("algorithm", [3, 2, 1], ids=["nullspace_mfma", "nullspace", "sweep"])
+@pytest.mark.parametrize("algorithm", [4, 3, 2, 1], ids=["nullspace_16l", "nullspace_mfma", "nullspace", "sweep"])
 @pytest.mark.parametrize("name", ["ik_qpoases_v050_b1024.npz", "ik_qpoases_v030_b512.npz", "ik_osqp_b512.npz"])
 def test_ik_matches_golden(wca, golden_dir, name, algorithm):
     g = _load(golden_dir, name)
@@ -200,7 +200,7 @@ def test_ik_matches_golden(wca, golden_dir, name, algorithm):
     assert np.array_equal(out["active_upper"][cc], g["active_upper"][cc])
 
 
-@pytest.mark.parametrize("algorithm", [3, 2, 1], ids=["nullspace_mfma", "nullspace", "sweep"])
+@pytest.mark.parametrize("algorithm", [4, 3, 2, 1], ids=["nullspace_16l", "nullspace_mfma", "nullspace", "sweep"])
 @pytest.mark.parametrize("form,vmax", [("qpoases", 0.4), ("qpoases", 0.22), ("osqp", 0.3)])
 def test_ik_against_oracle_live(wca, qs, form, vmax, algorithm):
     B = 160
@@ -237,7 +237,7 @@ def test_ik_osqp_form_quirks(wca, qs):
     assert np.abs(a["dq"] - q["dq"]).max() > 1e-3
 
 
-@pytest.mark.parametrize("algorithm", [3, 2, 1], ids=["nullspace_mfma", "nullspace", "sweep"])
+@pytest.mark.parametrize("algorithm", [4, 3, 2, 1], ids=["nullspace_16l", "nullspace_mfma", "nullspace", "sweep"])
 def test_ik_com_as_cost_variant(wca, qs, algorithm):
     """useCoMAsConstraint = 0: 12 equality rows, CoM task moves into the cost."""
     B = 48
@@ -259,7 +259,7 @@ def test_ik_stance_foot_touches_only_the_base(wca, qs):
     b = wca.synth.synth_ik_batch(B, seed=23)
     JL = b["J_left"].copy(); JL[:, :, 6:] = 0.0
     p = qs.IKParams(v_max=5.0 * np.ones(23))
-    for alg in (3, 2, 1):
+    for alg in (4, 3, 2, 1):
         out = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=5.0, algorithm=alg).solve_host(JL, b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
         for i in range(B):
             x = qs.ik_inputs_from_batch(dict(b, J_left=JL), i)

@@ -8,7 +8,7 @@ d = {k: torch.from_numpy(ib[k]).to(dev) for k in ("J_left", "J_right", "J_neck",
 dq = torch.zeros(B, 23, dtype=torch.float64, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
 sp = torch.cuda.current_stream().cuda_stream
 out = {}
-for alg in (2, 3):
+for alg in (2, 3, 4):
     ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=float(sys.argv[2]) if len(sys.argv) > 2 else 100.0, algorithm=alg)
     run = lambda: ik.solve_device(B, d["J_left"].data_ptr(), d["J_right"].data_ptr(), d["J_neck"].data_ptr(), d["J_com"].data_ptr(), d["q"].data_ptr(), d["state"].data_ptr(), dq.data_ptr(), st.data_ptr(), 0, 0, 0, 0, sp)
     for _ in range(5): run()

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WCQP_LIB_PATH") or os.path.join(_HERE, "libwcqp.so") 
 WCQP_OK = 0
 STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_OUTSIDE_HULL, STATUS_NUMERIC = range(5)
 IK_FORM_QPOASES, IK_FORM_OSQP = 0, 1
-IK_ALG_DEFAULT, IK_ALG_SWEEP, IK_ALG_NULLSPACE, IK_ALG_NULLSPACE_MFMA = 0, 1, 2, 3
+IK_ALG_DEFAULT, IK_ALG_SWEEP, IK_ALG_NULLSPACE, IK_ALG_NULLSPACE_MFMA, IK_ALG_NULLSPACE_16L = 0, 1, 2, 3, 4
 HULL_ROWS = 8
 MAX_DOF = 32
 IK_STATE_LEN = 87

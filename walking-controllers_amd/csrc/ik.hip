@@ -439,7 +439,7 @@ int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out) {
     if (!params || !out) return WCQP_E_INVALID;
     if (params->dof != kDof) return WCQP_E_UNSUPPORTED;      // kernels are unrolled for iCub's 23 DoF
     if (params->form != WCQP_IK_FORM_QPOASES && params->form != WCQP_IK_FORM_OSQP) return WCQP_E_INVALID;
-    if (params->algorithm < 0 || params->algorithm > WCQP_IK_ALG_NULLSPACE_MFMA) return WCQP_E_INVALID;
+    if (params->algorithm < 0 || params->algorithm > WCQP_IK_ALG_NULLSPACE_16L) return WCQP_E_INVALID;
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < r; ++c)          // the kernels use W J and J'W interchangeably: symmetric weights only
             if (params->neck_weight[3 * r + c] != params->neck_weight[3 * c + r] ||
@@ -493,6 +493,9 @@ int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
     if (batch == 0) return WCQP_OK;
     const int rc = ensure_device(h);
     if (rc != WCQP_OK) return rc;
+    if (h->p.algorithm == WCQP_IK_ALG_NULLSPACE_16L && h->p.use_com_as_constraint)
+        return wcqp_ik::ik3_launch(h->d_prm, batch, J_left, J_right, J_neck, J_com, q, state, dq, status,
+                                   active_lower, active_upper, foot_err, iters, (hipStream_t)stream);
     if (h->p.algorithm != WCQP_IK_ALG_SWEEP)
         return wcqp_ik::ik2_launch(h->d_prm, h->p.use_com_as_constraint != 0, h->p.algorithm != WCQP_IK_ALG_NULLSPACE, batch, J_left, J_right, J_neck, J_com,
                                    q, state, dq, status, active_lower, active_upper, foot_err, iters, (hipStream_t)stream);

@@ -42,26 +42,31 @@ struct Ik2Layout {
     static constexpr int NN = kNV - MEQ;                // free (non-basic) variables
     static constexpr int NK = NN + 1;                   // compact slots: free variables + the rhs lane
     static constexpr int KMAX = NN;
-    // persistent
-    static constexpr int OFF_FK = 0;                    // [NK][kLDF]   F columns by compact index (slot NN = b')
-    static constexpr int OFF_P = OFF_FK + NK * kLDF;
-    // phase A (set-up)
-    // MFMA variant: K-major operand tables X^T, Y^T [20][16] of the reduced-Hessian Gram product
-    // overlay the state block and the pivot columns (both dead by then); the 16x16 result tile
-    // [16][LDH] overlays X^T again (its writes depend on the MFMA results, i.e. follow every read)
+    static_assert(!USE_MFMA || (USE_COM && NK <= 16 && MEQ + NCOST <= 20), "one 16x16x20 MFMA tile");
+    // persistent: F = A_B^-1 A_N with the rhs column b' in slot NN.
+    //   VALU variant: columns by compact index, F_STORE[k * kLDF + r]
+    //   MFMA variant: the K-major operand table Y^T [20][16] of the Gram product doubles as the
+    //   store of F (rows 0..MEQ-1: Y^T[r][k] = F[r][k]); rows MEQ.. hold (W N Z)' and zero padding
+    static constexpr int OFF_F = 0;
+    static constexpr int F_SIZE = USE_MFMA ? 20 * 16 : NK * kLDF;
+    static constexpr int OFF_YT = OFF_F;
+    static constexpr int OFF_P = OFF_F + F_SIZE;
+    // phase A (set-up), all inside the region that the active set reuses afterwards
+    static constexpr int OFF_ST = OFF_P;                // [112] state + q (dead after the gradient)
+    static constexpr int OFF_CB = OFF_ST + 112;         // [4][16] entries of a panel's 4 pivot columns
+    static constexpr int OFF_RD = OFF_CB + 64;          // [16][8] per row r: {D, g, cost-row entries} of its basic variable
+    // MFMA variant: X^T [20][16] is written after the last read of ST / CB / RD and overlays them;
+    // the 16x16 result tile [16][LDH] overlays X^T again (its writes depend on the MFMA results,
+    // i.e. follow every read); the sweep's buffers overlay the tile once the rows are in registers
     static constexpr int LDH = 18;
     static constexpr int OFF_XT = OFF_P;
-    static constexpr int OFF_YT = OFF_XT + 20 * 16;
     static constexpr int OFF_HM = OFF_XT;
-    static constexpr int OFF_ST = OFF_P;                // [112] state + q
-    static constexpr int OFF_CB = OFF_ST + 112;         // [2][16] pivot column, double-buffered
-    static constexpr int OFF_RD = (USE_MFMA ? OFF_YT + 20 * 16 : OFF_CB + 32);   // [16][8] per row r: {D, g, cost-row entries} of its basic variable
-    static constexpr int OFF_WNZ = OFF_RD + 16 * 8;     // [NK][NCOST + (NCOST & 1)]  (VALU variant only)
     static constexpr int LDW = NCOST + (NCOST & 1);
-    static constexpr int OFF_COL = OFF_WNZ + (USE_MFMA ? 0 : NK * LDW);  // [2][32] sweep columns, double-buffered
+    static constexpr int OFF_WNZ = OFF_RD + 16 * 8;     // [NK][LDW]  (VALU variant only)
+    static constexpr int OFF_COL = OFF_P;               // [2][32] sweep columns, double-buffered (ST / CB / tile are dead by then)
     static constexpr int OFF_GR = OFF_COL + 64;         // [32] reduced gradient / x_N by compact index
-    static constexpr int END_A = OFF_GR + 32;
-    static_assert(!USE_MFMA || (USE_COM && NK <= 16 && MEQ + NCOST <= 20), "one 16x16x20 MFMA tile");
+    static constexpr int END_A = USE_MFMA ? OFF_XT + 20 * 16 : OFF_WNZ + NK * LDW;
+    static_assert(OFF_GR + 32 <= OFF_RD && OFF_RD + 128 <= END_A, "sweep buffers overlay ST/CB only; RD inside the region");
     // phase B (active set) reuses the phase-A area
     static constexpr int LDR = KMAX | 1;                // odd leading dim: row-per-lane accesses spread over banks
     static constexpr int OFF_RINV = OFF_P;              // [KMAX][LDR]
@@ -80,7 +85,10 @@ struct Ik2Layout {
 
 template <bool USE_COM, bool USE_MFMA>
 // 2 waves/SIMD: at 3 the allocator spills ~50 B/lane to scratch, which costs more than the extra wave buys
-__global__ __launch_bounds__(64, 2)
+#ifndef WCQP_IK2_WAVES
+#define WCQP_IK2_WAVES 2
+#endif
+__global__ __launch_bounds__(64, WCQP_IK2_WAVES)
 void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
                 const double* __restrict__ JN, const double* __restrict__ JC,
@@ -101,7 +109,9 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const bool live = inst_raw < batch;
     const long inst = live ? inst_raw : (long)batch - 1;
     double* S = smem[half];
-    double* Fk = S + L::OFF_FK;
+    double* Fst = S + L::OFF_F;
+    // entry (row r, compact column k) of F; see Ik2Layout
+    auto F_at = [&](int k, int r) -> double& { return USE_MFMA ? Fst[r * 16 + k] : Fst[k * kLDF + r]; };
     double* st = S + L::OFF_ST;
     double* bvec = S + L::OFF_B;
     const double inf = std::numeric_limits<double>::infinity();
@@ -113,28 +123,31 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     // per-variable constants first: their L2 latency hides under the Jacobian loads instead of
     // being exposed where they are consumed
     double Di = prm->lam[i], kq_i = prm->kq[i], qreg_i = prm->qreg[i];
-    double lo = var ? prm->vlo[i] : -inf, hi = var ? prm->vhi[i] : inf;
     double a[MEQ];          // column i of A = [J_left; J_right; (J_com)]; on lane 29: b
     double cn[NCOST];       // column i of the cost rows [ (J_com;) J_neck ]
     {
-        const double* jl = JL + inst * (6 * kNV);
-        const double* jr = JR + inst * (6 * kNV);
-        const double* jc = JC + inst * (3 * kNV);
-        const double* jn = JN + inst * (3 * kNV);
+        // lanes 29..31 own no variable: they load column 28 again (no predicated loads, which hipcc
+        // turns into one branch each); lane 29's copy is replaced by b below and nothing ever
+        // reads what lanes 30/31 compute
+        const int ic = var ? i : kNV - 1;
+        const double* jl = JL + inst * (6 * kNV) + ic;
+        const double* jr = JR + inst * (6 * kNV) + ic;
+        const double* jc = JC + inst * (3 * kNV) + ic;
+        const double* jn = JN + inst * (3 * kNV) + ic;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) a[r] = var ? jl[r * kNV + i] : 0.0;
+        for (int r = 0; r < 6; ++r) a[r] = jl[r * kNV];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) a[6 + r] = var ? jr[r * kNV + i] : 0.0;
+        for (int r = 0; r < 6; ++r) a[6 + r] = jr[r * kNV];
         if constexpr (USE_COM) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) a[12 + r] = var ? jc[r * kNV + i] : 0.0;
+            for (int r = 0; r < 3; ++r) a[12 + r] = jc[r * kNV];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) cn[r] = var ? jn[r * kNV + i] : 0.0;
+            for (int r = 0; r < 3; ++r) cn[r] = jn[r * kNV];
         } else {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) cn[r] = var ? jc[r * kNV + i] : 0.0;
+            for (int r = 0; r < 3; ++r) cn[r] = jc[r * kNV];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) cn[3 + r] = var ? jn[r * kNV + i] : 0.0;
+            for (int r = 0; r < 3; ++r) cn[3 + r] = jn[r * kNV];
         }
         const double* sp = state + inst * kStateLen;
         st[i] = sp[i];
@@ -194,33 +207,84 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 
     WCQP_STAMP(2);
     // ---------------- phase 2: Gauss-Jordan with column pivoting --------------------------
-    bool basic = false;
-    int myrow = 0;
-    bool ok = true;
+    int myrow = -1;             // row in which this lane's variable is basic (-1: free)
+    unsigned kmin = 0xffffffffu; // smallest pivot key met (|pivot| as float bits)
     {
-        double* cbase = S + L::OFF_CB;
+        // Blocked: rows are taken in panels of 4.  Inside a panel only the panel's own rows are
+        // reduced, so a step moves 4 doubles (3 entries + 1/pivot) of the pivot lane, by v_readlane
+        // into SGPRs (VALU has headroom, the CU-shared LDS pipe has none); 1/pivot is computed by
+        // EVERY lane for its own entry while the arg-max runs, off the serial chain.  The
+        // other 11 rows then get the panel's rank-4 update  a[q] -= sum_s C[q][s] T[s]  at once:
+        // the 4 pivot lanes publish their (still untouched) entries C of those rows in the SAME
+        // store instructions - an LDS store costs per instruction, not per lane, so 24 stores per
+        // instance pair replace the 120 of a column-at-a-time Gauss-Jordan (they were 2/3 of the
+        // kernel's LDS-pipe time, and the LDS pipe is what bounds this kernel at scale).
+        double* cb = S + L::OFF_CB;
 #pragma unroll
-        for (int r = 0; r < MEQ; ++r) {
-            const int pl = group_argmax_abs(a[r], var && !basic, i);
-            double* cb = cbase + 16 * (r & 1);
-            if (i == pl) {
-                basic = true; myrow = r;
+        for (int r0 = 0; r0 < MEQ; r0 += 4) {
+            const int pw = (MEQ - r0 < 4) ? MEQ - r0 : 4;
 #pragma unroll
-                for (int q = 0; q < MEQ; ++q) cb[q] = a[q];
+            for (int s = 0; s < pw; ++s) {
+                const int r = r0 + s;
+                const double rinv_mine = wcqp::fast_rcp(a[r]);
+                unsigned key;
+                const int pl = group_argmax_abs(a[r], var && myrow < 0, i, key);
+                kmin = min(kmin, key);
+                myrow = (i == pl) ? r : myrow;
+                wcqp::pin_value(kmin);
+                wcqp::pin_value(myrow);
+                // the pivot lane of each instance is wave-uniform once read into an SGPR, and so are
+                // its panel entries: v_readlane puts them in SGPRs that feed the FMAs directly
+                const int pl0 = __builtin_amdgcn_readlane(pl, 0);
+                const int pl1 = __builtin_amdgcn_readlane(pl, 32) + 32;
+                if (half == 0) {
+                    const double t = a[r] * lane_value(rinv_mine, pl0);
+#pragma unroll
+                    for (int u = 0; u < pw; ++u) {
+                        if (u != s) a[r0 + u] = fma(-lane_value(a[r0 + u], pl0), t, a[r0 + u]);
+                    }
+                    a[r] = t;
+                } else {
+                    const double t = a[r] * lane_value(rinv_mine, pl1);
+#pragma unroll
+                    for (int u = 0; u < pw; ++u) {
+                        if (u != s) a[r0 + u] = fma(-lane_value(a[r0 + u], pl1), t, a[r0 + u]);
+                    }
+                    a[r] = t;
+                }
+                if (r0 == 4) WCQP_STAMP(10 + s);        // diagnostic build: second panel, step by step
+            }
+            if (myrow >= r0) {
+                double* c = cb + (myrow - r0) * 16;
+#pragma unroll
+                for (int q = 0; q < MEQ; q += 2) {
+                    if (q >= r0 && q < r0 + 4) continue;                  // the panel's own rows are done
+                    *reinterpret_cast<double2*>(c + q) = make_double2(a[q], q + 1 < MEQ ? a[q + 1] : 0.0);
+                }
             }
             wcqp::wave_lds_fence();
-            const double piv = cb[r];
-            ok = ok && (fabs(piv) > 1e-12);
-            const double t = a[r] * wcqp::fast_rcp(piv);
 #pragma unroll
             for (int q = 0; q < MEQ; q += 2) {
-                const double2 c2 = *reinterpret_cast<const double2*>(cb + q);
-                if (q != r) a[q] = fma(-c2.x, t, a[q]);
-                if (q + 1 < MEQ && q + 1 != r) a[q + 1] = fma(-c2.y, t, a[q + 1]);
+                if (q >= r0 && q < r0 + 4) continue;
+                double acc0 = a[q], acc1 = q + 1 < MEQ ? a[q + 1] : 0.0;
+#pragma unroll
+                for (int s = 0; s < pw; ++s) {
+                    const double2 c2 = *reinterpret_cast<const double2*>(cb + s * 16 + q);
+                    acc0 = fma(-c2.x, a[r0 + s], acc0);
+                    acc1 = fma(-c2.y, a[r0 + s], acc1);
+                }
+                a[q] = acc0;
+                if (q + 1 < MEQ) a[q + 1] = acc1;
+                // at most half a panel's column reads in flight: all 24 at once cost 96 VGPRs
+                if (q == (r0 < 8 ? 8 : 4)) wcqp::pin_result(a[q]);
             }
-            a[r] = t;
+            wcqp::wave_lds_fence();
+            if (r0 == 0) WCQP_STAMP(14);
+            if (r0 == 4) WCQP_STAMP(15);
         }
     }
+    const bool basic = myrow >= 0;
+    bool ok = __uint_as_float(kmin & ~31u) > 1e-12f;
     // compact index of the free lanes (prefix count inside the 32-lane group); rhs lane -> slot NN
     const bool free_var = var && !basic;
     const unsigned long long fm = __ballot(free_var);
@@ -240,11 +304,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
     if (rowlane) {
 #pragma unroll
-        for (int r = 0; r < MEQ; ++r) Fk[kap_i * kLDF + r] = a[r];
-        if constexpr (USE_MFMA) {
-#pragma unroll
-            for (int r = 0; r < MEQ; ++r) S[L::OFF_YT + r * 16 + kap_i] = a[r];     // Y^T rows 0..MEQ-1 = F
-        }
+        for (int r = 0; r < MEQ; ++r) F_at(kap_i, r) = a[r];                    // MFMA: Y^T rows 0..MEQ-1 = F
     }
     wcqp::wave_lds_fence();
     // one pass over the rows: nz = column of N Z (rhs lane: -N x_p), g_r partial, a := F_j[r] D_B[r]
@@ -263,8 +323,8 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             if (s + 1 < NCOST) nz[s + 1] = fma(-n2.y, ar, nz[s + 1]);
         }
         gr = fma(-ar, dg.y, gr);
-        a[r] = ar * dg.x;       // F itself now lives in Fk
-        if ((r & 3) == 3) wcqp::pin_result(gr);
+        a[r] = ar * dg.x;       // F itself now lives in LDS
+        if (r & 1) wcqp::pin_result(gr);
     }
     {
         double w[NCOST];
@@ -279,6 +339,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             }
         }
         if constexpr (USE_MFMA) {
+            wcqp::wave_lds_fence();      // X^T overlays RD: every lane's row pass has read it by now
             if (rowlane) {
 #pragma unroll
                 for (int r = 0; r < MEQ; ++r) S[L::OFF_XT + r * 16 + kap_i] = a[r];   // X^T rows 0..MEQ-1 = F D_B
@@ -343,7 +404,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         double acc = 0.0;
 #pragma unroll
         for (int r = 0; r < MEQ; r += 2) {
-            const double2 f2 = *reinterpret_cast<const double2*>(Fk + k * kLDF + r);
+            const double2 f2 = *reinterpret_cast<const double2*>(Fst + k * kLDF + r);
             acc = fma(a[r], f2.x, acc);
             if (r + 1 < MEQ) acc = fma(a[r + 1], f2.y, acc);
         }
@@ -362,6 +423,9 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     gr -= Hr[NN];               // g_r = g_j - F_j' g_B - (b'-dependent column)
 
     WCQP_STAMP(5);
+    // bounds of this variable: fetched here so that the (L2) latency hides under the sweep and
+    // the two registers are not carried through the set-up phases
+    double lo = prm->vlo[i], hi = prm->vhi[i];
     // ---------------- phase 4: Hr^-1 (sweep over the NN compact pivots), x_N, x_B ---------
     {
         double* col = S + L::OFF_COL;
@@ -404,9 +468,9 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     wcqp::wave_lds_fence();
     double nu = free_var ? xn : 0.0;
     if (basic) {
-        double acc = Fk[NN * kLDF + myrow];                      // b'
+        double acc = F_at(NN, myrow);                            // b'
 #pragma unroll
-        for (int k = 0; k < NN; ++k) acc = fma(-Fk[k * kLDF + myrow], grv[k], acc);
+        for (int k = 0; k < NN; ++k) acc = fma(-F_at(k, myrow), grv[k], acc);
         nu = acc;
     }
     wcqp::wave_lds_fence();
@@ -418,6 +482,8 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     bool in_w = false;
     double my_sig = 0.0;
     const double tol = prm->tol;
+    lo = var ? lo : -inf;
+    hi = var ? hi : inf;
     const bool need = !osqp_form && var && i >= 6 && fmax(nu - hi, lo - nu) > tol;
     if (__ballot(need) != 0ull) {
         const GiScratch w{S + L::OFF_RINV, S + L::OFF_V0, S + L::OFF_V1, S + L::OFF_V2,
@@ -440,7 +506,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             double tfree = 0.0;
             if (p_basic) {
 #pragma unroll
-                for (int k = 0; k < NN; ++k) tfree = fma(Hr[k], Fk[k * kLDF + p_idx], tfree);   // -Hinv F[row_p,:]'
+                for (int k = 0; k < NN; ++k) tfree = fma(Hr[k], F_at(k, p_idx), tfree);   // -Hinv F[row_p,:]'
             } else if (free_var) {
                 tfree = tkb[kap_i];
             }
@@ -451,7 +517,7 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             if (basic) {
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < NN; ++k) acc = fma(-Fk[k * kLDF + myrow], tkb[k], acc);
+                for (int k = 0; k < NN; ++k) acc = fma(-F_at(k, myrow), tkb[k], acc);
                 tp = acc;
             }
             wcqp::wave_lds_fence();
@@ -479,13 +545,13 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     return;
 #endif
     if (ferr_out) {
-        double* nub = S + L::OFF_FK;                 // F is dead now
+        double* nub = S + L::OFF_F;                  // F is dead now
         wcqp::wave_lds_fence();
         nub[i] = var ? nu : 0.0;
         wcqp::wave_lds_fence();
         if (i < 12 && live) {
             const double* jrow = (i < 6 ? JL + inst * (6 * kNV) + i * kNV : JR + inst * (6 * kNV) + (i - 6) * kNV);
-            double acc = b_mine;
+            double acc = bvec[i];
             for (int k = 0; k < kNV; ++k) acc = fma(-jrow[k], nub[k], acc);
             ferr_out[inst * 12 + i] = acc;           // b - J nu (osqp.cpp:430-454, qp.cpp:364-401)
         }

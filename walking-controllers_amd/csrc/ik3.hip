@@ -1,0 +1,703 @@
+// Jacobian QP-IK, third kernel: the null-space formulation of ik2.hip on 16 lanes per instance
+// (four instances per wave64, one DPP row each).
+//
+// Same QP, inputs, outputs and reference citations as ik.hip / ik2.hip.  Why another layout:
+// s_memtime stamps and latency micro-benchmarks (tools/ubench/lat.hip) showed that the kernel is
+// a chain of ~45 serial cross-lane steps (arg-max ~110 cycles, crossbar / LDS round trip ~75,
+// v_readlane -> use ~40) in which a dependent fp64 FMA costs 4 cycles: the steps cost the same
+// whether they serve 2 instances per wave or 4, and the FMAs between them are almost free.  So
+//   * lane j of an instance's 16 owns TWO columns of [A | b]: j and j + 16 (column 29 = b);
+//   * an instance is one DPP row: every reduction is 4 DPP steps, no row exchange;
+//   * the reduced Hessian row k lives on lane k (k = compact index), not on the variable's lane;
+//   * the Gram product is one fp64 MFMA tile per instance, X' = D_B F formed on the fly.
+// LDS is 640 doubles per instance (20 KB per block: 8 blocks per CU = the whole 160 KB).
+#include <cmath>
+#include <limits>
+#include "ik_common.h"
+
+namespace {
+
+using namespace wcqp_ik;
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int MEQ = 15;               // equality rows (CoM as constraint)
+constexpr int NCOST = 3;              // cost rows: J_neck
+constexpr int NN = kNV - MEQ;         // 14 free variables
+constexpr int KMAX = NN;
+constexpr int LDR = KMAX | 1;         // 15
+constexpr int LDH = 18;
+
+// ---- LDS layout per instance (doubles) ---------------------------------------------------------
+constexpr int OFF_F = 0;              // [15][16]  F[r][k] = (A_B^-1 A_N)[r][k], column NN = b'
+constexpr int OFF_P = 240;
+//   set-up
+constexpr int OFF_ST = OFF_P;         // [112] state + q (dead after the gradient)
+constexpr int OFF_CB = OFF_P + 112;   // [4][16] entries of a panel's 4 pivot columns
+constexpr int OFF_RD = OFF_P + 176;   // [16][8] per row r: {D, g, neck-row entries} of its basic variable
+constexpr int OFF_GRV = OFF_P + 304;  // [16] reduced gradient by compact index
+constexpr int OFF_DN = OFF_P + 320;   // [16] Lambda entry of the free variable with compact index k
+constexpr int OFF_YTT = OFF_P;        // [5][16] rows 15..19 of Y^T: (W N Z)' and zero padding  (over ST)
+constexpr int OFF_XTT = OFF_P + 80;   // [5][16] rows 15..19 of X^T: (N Z)' and zero padding    (over ST/CB)
+constexpr int OFF_HM = OFF_P;         // [16][LDH] Gram tile (over everything up to RD, all dead by then)
+constexpr int OFF_COL = OFF_P;        // [2][16] sweep columns (over the tile once its rows are in registers)
+constexpr int OFF_XNV = OFF_P + 32;   // [16] x_N by compact index
+constexpr int OFF_XBV = OFF_P + 48;   // [16] x_B by row
+//   active set (over the set-up area)
+constexpr int OFF_RINV = OFF_P;       // [KMAX][LDR]
+constexpr int OFF_TPB = OFF_P + 212;  // [32] column tau_p by variable
+constexpr int OFF_ZB = OFF_P + 244;   // [32] sign / primal step by variable
+constexpr int OFF_SV = OFF_P + 276;   // [32] violation by variable
+constexpr int OFF_RV = OFF_P + 308;   // [16] dual step per slot
+constexpr int OFF_CV = OFF_P + 324;   // [16]
+constexpr int OFF_TKB = OFF_P + 340;  // [16] t by compact index
+constexpr int OFF_TBV = OFF_P + 356;  // [16] -F t by row
+constexpr int OFF_WI = OFF_P + 372;   // [16] ints: variable of slot a
+constexpr int OFF_INFO = OFF_P + 380; // [4]
+constexpr int OFF_B = OFF_P + 384;    // [16] task rhs (kept for the foot errors)
+constexpr int PER_INST = OFF_B + 16;  // 640
+static_assert(OFF_DN + 16 <= OFF_B && OFF_INFO + 4 <= OFF_B && OFF_HM + 16 * LDH <= OFF_GRV, "LDS overlays");
+static_assert(PER_INST * 8 * 4 * 8 <= 160 * 1024, "8 blocks per CU");
+
+#ifdef WCQP_IK_STAMPS
+#define WCQP_STAMP(k) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+                           if (lane == 0) reinterpret_cast<unsigned long long*>(ferr_out)[(size_t)blockIdx.x * 16 + (k)] = t__; } while (0)
+#else
+#define WCQP_STAMP(k) do { } while (0)
+#endif
+
+// all-reduce over the 16 lanes of a DPP row
+__device__ __forceinline__ unsigned row_max_u32(unsigned key) {
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x141, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x140, 0xf, 0xf, false));
+    return key;
+}
+__device__ __forceinline__ double row_min(double v) {
+    v = fmin(v, dpp_move<0xB1>(v));
+    v = fmin(v, dpp_move<0x4E>(v));
+    v = fmin(v, dpp_move<0x141>(v));
+    v = fmin(v, dpp_move<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ double row_max(double v) {
+    v = fmax(v, dpp_move<0xB1>(v));
+    v = fmax(v, dpp_move<0x4E>(v));
+    v = fmax(v, dpp_move<0x141>(v));
+    v = fmax(v, dpp_move<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned mag_key(double v) { return __float_as_uint((float)fabs(v)) & ~31u; }
+
+__global__ __launch_bounds__(64, 2)
+void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
+                const double* __restrict__ JL, const double* __restrict__ JR,
+                const double* __restrict__ JN, const double* __restrict__ JC,
+                const double* __restrict__ qpos, const double* __restrict__ state,
+                double* __restrict__ dq_out, int* __restrict__ status_out,
+                unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
+                double* __restrict__ ferr_out, int* __restrict__ iters_out)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
+
+    const int lane = threadIdx.x;
+    const int grp = lane >> 4;
+    const int j = lane & 15;                        // owns columns j (slot 0) and j + 16 (slot 1)
+    const long inst_raw = (long)blockIdx.x * 4 + grp;
+    const bool live = inst_raw < batch;
+    const long inst = live ? inst_raw : (long)batch - 1;
+    double* S = smem[grp];
+    double* F = S + OFF_F;
+    double* st = S + OFF_ST;
+    double* bvec = S + OFF_B;
+    const double inf = std::numeric_limits<double>::infinity();
+    const bool var1 = j < kNV - 16;                 // column j + 16 is a variable (j < 13)
+    const bool rhs1 = j == kNV - 16;                // column 29 = b
+    const int col1 = j + 16;
+
+    WCQP_STAMP(0);
+    // ---------------- phase 0: loads ------------------------------------------------------------
+    const double Di0 = prm->lam[j], Di1 = prm->lam[col1];
+    double a0[MEQ], a1[MEQ];    // columns j and j + 16 of A = [J_left; J_right; J_com]; lane 13 slot 1: b
+    double cn0[NCOST], cn1[NCOST];
+    {
+        const int c1 = var1 ? col1 : kNV - 1;       // lanes 13..15 reload column 28 (never used)
+        const double* jl = JL + inst * (6 * kNV);
+        const double* jr = JR + inst * (6 * kNV);
+        const double* jc = JC + inst * (3 * kNV);
+        const double* jn = JN + inst * (3 * kNV);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { a0[r] = jl[r * kNV + j]; a1[r] = jl[r * kNV + c1]; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { a0[6 + r] = jr[r * kNV + j]; a1[6 + r] = jr[r * kNV + c1]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { a0[12 + r] = jc[r * kNV + j]; a1[12 + r] = jc[r * kNV + c1]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cn0[r] = jn[r * kNV + j]; cn1[r] = jn[r * kNV + c1]; }
+        const double* sp = state + inst * kStateLen;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) st[m * 16 + j] = sp[m * 16 + j];
+        if (80 + j < kStateLen) st[80 + j] = sp[80 + j];
+        st[kStateLen + j] = qpos[inst * kDof + j];
+        if (16 + j < kDof) st[kStateLen + 16 + j] = qpos[inst * kDof + 16 + j];
+    }
+    wcqp::wave_lds_fence();
+
+    WCQP_STAMP(1);
+    // ---------------- phase 1: task rhs b (lane r < MEQ) and gradient g ---------------------------
+    const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
+    if (j < MEQ) {
+        double b_mine;
+        if (j < 12) {
+            const int foot = j / 6, k = j % 6;
+            const double* p  = st + (foot ? 12 : 0);
+            const double* R  = st + (foot ? 15 : 3);
+            const double* pd = st + (foot ? 36 : 24);
+            const double* Rd = st + (foot ? 39 : 27);
+            const double* tw = st + (foot ? 81 : 75);
+            const double corr = k < 3 ? prm->k_pos_foot * (p[k] - pd[k]) : prm->k_att_foot * rot_err(R, Rd, k - 3);
+            const bool skip = osqp_form && tw[0] == tw[1] && tw[0] == 0.0;        // osqp.cpp:286-306
+            b_mine = skip ? tw[k] : tw[k] - corr;
+        } else {
+            const int k = j - 12;
+            b_mine = st[72 + k] - prm->k_pos_com * (st[66 + k] - st[69 + k]);
+        }
+        bvec[j] = b_mine;
+    }
+    double g0, g1;              // gradient entries (osqp.cpp:181-196, qp.cpp:161-178)
+    {
+        const double kap = prm->kappa * (-prm->k_neck);
+        const double e0 = kap * rot_err(st + 48, st + 57, 0);
+        const double e1 = kap * rot_err(st + 48, st + 57, 1);
+        const double e2 = kap * rot_err(st + 48, st + 57, 2);
+        const double y0 = prm->Wn[0] * e0 + prm->Wn[1] * e1 + prm->Wn[2] * e2;
+        const double y1 = prm->Wn[3] * e0 + prm->Wn[4] * e1 + prm->Wn[5] * e2;
+        const double y2 = prm->Wn[6] * e0 + prm->Wn[7] * e1 + prm->Wn[8] * e2;
+        g0 = -(cn0[0] * y0 + cn0[1] * y1 + cn0[2] * y2);
+        if (j >= 6) g0 -= prm->kq[j] * (prm->qreg[j] - st[kStateLen + j - 6]);
+        g1 = -(cn1[0] * y0 + cn1[1] * y1 + cn1[2] * y2);
+        g1 -= prm->kq[col1] * (prm->qreg[col1] - st[kStateLen + (var1 ? j + 10 : 0)]);
+        g1 = var1 ? g1 : 0.0;
+    }
+    wcqp::wave_lds_fence();
+    if (rhs1) {
+#pragma unroll
+        for (int r = 0; r < MEQ; ++r) a1[r] = bvec[r];
+    }
+
+    WCQP_STAMP(2);
+    // ---------------- phase 2: Gauss-Jordan with column pivoting, panels of 4 rows ---------------
+    int myrow0 = -1, myrow1 = -1;      // row in which column j / j + 16 is basic (-1: free)
+    unsigned kmin = 0xffffffffu;
+    {
+        double* cb = S + OFF_CB;
+        const int rowbase = lane & 48;
+#pragma unroll
+        for (int r0 = 0; r0 < MEQ; r0 += 4) {
+            const int pw = (MEQ - r0 < 4) ? MEQ - r0 : 4;
+#pragma unroll
+            for (int s = 0; s < pw; ++s) {
+                const int r = r0 + s;
+                // this lane's better candidate; its panel entries are what the lane would publish
+                const unsigned k0 = (myrow0 < 0) ? (mag_key(a0[r]) | (unsigned)(31 - j)) : 0u;
+                const unsigned k1 = (var1 && myrow1 < 0) ? (mag_key(a1[r]) | (unsigned)(15 - j)) : 0u;
+                const bool best1 = k1 > k0;
+                double m[4];
+#pragma unroll
+                for (int u = 0; u < pw; ++u) m[u] = best1 ? a1[r0 + u] : a0[r0 + u];
+                m[s] = wcqp::fast_rcp(m[s]);            // 1 / pivot, speculatively on every lane
+                const unsigned key = row_max_u32(max(k0, k1));
+                kmin = min(kmin, key);
+                const int p = 31 - (int)(key & 31u);    // pivot column
+                myrow0 = (p == j) ? r : myrow0;
+                myrow1 = (p == col1) ? r : myrow1;
+                wcqp::pin_value(kmin);
+                wcqp::pin_value(myrow0);
+                wcqp::pin_value(myrow1);
+                const int src = (rowbase + (p & 15)) << 2;
+                double c[4];
+#pragma unroll
+                for (int u = 0; u < pw; ++u) c[u] = lane_gather(m[u], src);
+                const double t0 = a0[r] * c[s], t1 = a1[r] * c[s];
+#pragma unroll
+                for (int u = 0; u < pw; ++u) {
+                    if (u != s) { a0[r0 + u] = fma(-c[u], t0, a0[r0 + u]); a1[r0 + u] = fma(-c[u], t1, a1[r0 + u]); }
+                }
+                a0[r] = t0; a1[r] = t1;
+            }
+            // rank-pw update of the other rows; the pivot lanes publish their untouched entries of those rows
+            if (myrow0 >= r0) {
+                double* c = cb + (myrow0 - r0) * 16;
+#pragma unroll
+                for (int q = 0; q < MEQ; q += 2) {
+                    if (q >= r0 && q < r0 + 4) continue;
+                    *reinterpret_cast<double2*>(c + q) = make_double2(a0[q], q + 1 < MEQ ? a0[q + 1] : 0.0);
+                }
+            }
+            if (myrow1 >= r0) {
+                double* c = cb + (myrow1 - r0) * 16;
+#pragma unroll
+                for (int q = 0; q < MEQ; q += 2) {
+                    if (q >= r0 && q < r0 + 4) continue;
+                    *reinterpret_cast<double2*>(c + q) = make_double2(a1[q], q + 1 < MEQ ? a1[q + 1] : 0.0);
+                }
+            }
+            wcqp::wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < MEQ; q += 2) {
+                if (q >= r0 && q < r0 + 4) continue;
+                double x0 = a0[q], x1 = q + 1 < MEQ ? a0[q + 1] : 0.0;
+                double y0 = a1[q], y1 = q + 1 < MEQ ? a1[q + 1] : 0.0;
+#pragma unroll
+                for (int s = 0; s < pw; ++s) {
+                    const double2 c2 = *reinterpret_cast<const double2*>(cb + s * 16 + q);
+                    x0 = fma(-c2.x, a0[r0 + s], x0); x1 = fma(-c2.y, a0[r0 + s], x1);
+                    y0 = fma(-c2.x, a1[r0 + s], y0); y1 = fma(-c2.y, a1[r0 + s], y1);
+                }
+                a0[q] = x0; a1[q] = y0;
+                if (q + 1 < MEQ) { a0[q + 1] = x1; a1[q + 1] = y1; }
+                if (q == (r0 < 8 ? 8 : 4)) wcqp::pin_result(a0[q]);
+            }
+            wcqp::wave_lds_fence();
+        }
+    }
+    bool ok = __uint_as_float(kmin & ~31u) > 1e-12f;
+    // compact index of the free columns, in column order; the rhs column takes slot NN
+    const bool free0 = myrow0 < 0;
+    const bool free1 = var1 && myrow1 < 0;
+    int kap0, kap1;
+    {
+        const unsigned g0b = (unsigned)((__ballot(free0) >> (16 * grp)) & 0xffffull);
+        const unsigned g1b = (unsigned)((__ballot(free1) >> (16 * grp)) & 0xffffull);
+        const unsigned below = (1u << j) - 1u;
+        const int n0 = __popc(g0b);
+        kap0 = free0 ? __popc(g0b & below) : 31;
+        kap1 = free1 ? n0 + __popc(g1b & below) : (rhs1 ? NN : 31);
+        ok = ok && (n0 + __popc(g1b) == NN);
+        // a failed elimination must not index the tables out of range
+        kap0 = (kap0 < NN) ? kap0 : (free0 ? NN - 1 : 31);
+        kap1 = (kap1 <= NN) ? kap1 : (free1 ? NN - 1 : 31);
+    }
+    const bool own1 = free1 || rhs1;   // slot 1 owns a compact column (slot 0: free0)
+
+    WCQP_STAMP(3);
+    // ---------------- phase 3: tables for the reduced Hessian -------------------------------------
+    double* rd = S + OFF_RD;
+    if (!free0) {
+        double* d = rd + myrow0 * 8;
+        d[0] = Di0; d[1] = g0; d[2] = cn0[0]; d[3] = cn0[1]; d[4] = cn0[2];
+    }
+    if (var1 && !free1) {
+        double* d = rd + myrow1 * 8;
+        d[0] = Di1; d[1] = g1; d[2] = cn1[0]; d[3] = cn1[1]; d[4] = cn1[2];
+    }
+    if (free0) {
+#pragma unroll
+        for (int r = 0; r < MEQ; ++r) F[r * 16 + kap0] = a0[r];
+        S[OFF_DN + kap0] = Di0;
+    }
+    if (own1) {
+#pragma unroll
+        for (int r = 0; r < MEQ; ++r) F[r * 16 + kap1] = a1[r];
+        S[OFF_DN + kap1] = Di1;
+    }
+    wcqp::wave_lds_fence();
+    // one pass over the rows for both columns: nz = column of N Z (rhs: -N x_p), reduced gradient
+    double nz0[NCOST], nz1[NCOST];
+#pragma unroll
+    for (int s = 0; s < NCOST; ++s) { nz0[s] = cn0[s]; nz1[s] = rhs1 ? 0.0 : cn1[s]; }
+    double gr0 = g0, gr1 = g1;
+#pragma unroll
+    for (int r = 0; r < MEQ; ++r) {
+        const double2 dg = *reinterpret_cast<const double2*>(rd + r * 8);
+        const double2 n01 = *reinterpret_cast<const double2*>(rd + r * 8 + 2);
+        const double n2 = rd[r * 8 + 4];
+        nz0[0] = fma(-n01.x, a0[r], nz0[0]); nz0[1] = fma(-n01.y, a0[r], nz0[1]); nz0[2] = fma(-n2, a0[r], nz0[2]);
+        nz1[0] = fma(-n01.x, a1[r], nz1[0]); nz1[1] = fma(-n01.y, a1[r], nz1[1]); nz1[2] = fma(-n2, a1[r], nz1[2]);
+        gr0 = fma(-a0[r], dg.y, gr0);
+        gr1 = fma(-a1[r], dg.y, gr1);
+        if ((r & 3) == 3) wcqp::pin_result(gr0);
+    }
+    wcqp::wave_lds_fence();           // ST / CB are dead: the operand tails overlay them
+    {
+        double* ytt = S + OFF_YTT;
+        double* xtt = S + OFF_XTT;
+        if (free0) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                xtt[s * 16 + kap0] = nz0[s];
+                ytt[s * 16 + kap0] = prm->Wn[3 * s] * nz0[0] + prm->Wn[3 * s + 1] * nz0[1] + prm->Wn[3 * s + 2] * nz0[2];
+            }
+            S[OFF_GRV + kap0] = gr0;
+        }
+        if (own1) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                xtt[s * 16 + kap1] = nz1[s];
+                ytt[s * 16 + kap1] = prm->Wn[3 * s] * nz1[0] + prm->Wn[3 * s + 1] * nz1[1] + prm->Wn[3 * s + 2] * nz1[2];
+            }
+            S[OFF_GRV + kap1] = gr1;
+        }
+        // zero padding: reduction rows 18, 19 and the unused compact slot 15
+        xtt[3 * 16 + j] = 0.0; xtt[4 * 16 + j] = 0.0;
+        ytt[3 * 16 + j] = 0.0; ytt[4 * 16 + j] = 0.0;
+        if (j < 3) { xtt[j * 16 + 15] = 0.0; ytt[j * 16 + 15] = 0.0; }
+        if (j < MEQ) F[j * 16 + 15] = 0.0;
+    }
+    wcqp::wave_lds_fence();
+
+    WCQP_STAMP(4);
+    // [Hr | h_rhs] = X Y',  X = [F D_B | (N Z)'],  Y = [F | (W N Z)'],  K = 18 (padded to 20):
+    // one 16x16 fp64 MFMA tile per instance, fed by all 64 lanes (A[i = lane & 15][k = lane >> 4])
+    double Hr[NN + 1];
+    {
+        const int mk = lane & 15, mq = lane >> 4;
+        v4d acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int kk = 4 * s + mq;
+            const bool tail = kk >= MEQ;
+            const int oy = tail ? OFF_YTT + (kk - MEQ) * 16 + mk : OFF_F + kk * 16 + mk;
+            const int ox = tail ? OFF_XTT + (kk - MEQ) * 16 + mk : OFF_F + kk * 16 + mk;
+            const int od = tail ? OFF_RD : OFF_RD + kk * 8;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double yv = smem[g][oy];
+                const double xs = smem[g][ox];
+                const double dv = tail ? 1.0 : smem[g][od];
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs * dv, yv, acc[g], 0, 0, 0);
+            }
+        }
+        // C/D layout of the f64 tile: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) smem[g][OFF_HM + (mq + 4 * reg) * LDH + mk] = acc[g][reg];
+        }
+        wcqp::wave_lds_fence();
+        const double fm = j < NN ? 1.0 : 0.0;          // lanes 14, 15 carry zero rows
+        const double dn = S[OFF_DN + (j < NN ? j : 0)];
+        const double* hrow = S + OFF_HM + j * LDH;
+#pragma unroll
+        for (int k = 0; k <= NN; k += 2) {
+            const double2 h2 = *reinterpret_cast<const double2*>(hrow + k);
+            Hr[k] = fm * (h2.x + (k == j ? dn : 0.0));
+            if (k + 1 <= NN) Hr[k + 1] = fm * (h2.y + (k + 1 == j ? dn : 0.0));
+        }
+    }
+    const double gr = (j < NN ? S[OFF_GRV + j] : 0.0) - Hr[NN];   // g_r = g_j - F_j' g_B - (b'-dependent column)
+    wcqp::wave_lds_fence();
+
+    WCQP_STAMP(5);
+    // ---------------- phase 4: Hr^-1 (sweep over the NN pivots), x_N, x_B -------------------------
+    {
+        double* col = S + OFF_COL;
+        col[j] = Hr[0];
+        wcqp::wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < NN; ++k) {
+            double* cb = col + 16 * (k & 1);
+            double* nb = col + 16 * ((k + 1) & 1);
+            const double piv = cb[k];
+            ok = ok && (piv > 0.0);
+            const double d = wcqp::fast_rcp(piv);
+            const double f0 = Hr[k] * d;
+            const double f = (j == k) ? (1.0 - d) : f0;
+            if (k + 1 < NN) {
+                Hr[k + 1] = fma(-f, cb[k + 1], Hr[k + 1]);
+                nb[j] = Hr[k + 1];                        // publish the next column early
+            }
+#pragma unroll
+            for (int q = 0; q < NN; q += 2) {
+                const double2 c2 = *reinterpret_cast<const double2*>(cb + q);
+                if (q != k && q != k + 1) Hr[q] = fma(-f, c2.x, Hr[q]);
+                if (q + 1 < NN && q + 1 != k && q + 1 != k + 1) Hr[q + 1] = fma(-f, c2.y, Hr[q + 1]);
+            }
+            Hr[k] = (j == k) ? -d : f0;
+            wcqp::wave_lds_fence();
+        }
+    }
+    WCQP_STAMP(6);
+    // Hr now holds row j of -(Hr^-1) on lanes j < NN
+    double nu0, nu1;
+    {
+        double* xnv = S + OFF_XNV;
+        double* xbv = S + OFF_XBV;
+        xnv[j] = gr;                                      // reduced gradient by compact index
+        wcqp::wave_lds_fence();
+        double xn = 0.0;
+#pragma unroll
+        for (int k = 0; k < NN; k += 2) {
+            const double2 g2 = *reinterpret_cast<const double2*>(xnv + k);
+            xn = fma(Hr[k], g2.x, xn);
+            xn = fma(Hr[k + 1], g2.y, xn);
+        }
+        wcqp::wave_lds_fence();
+        xnv[j] = xn;                                      // x_N = -Hinv g_r
+        wcqp::wave_lds_fence();
+        {
+            const double* frow = F + (j < MEQ ? j : 0) * 16;
+            double acc = frow[NN];                        // b'
+#pragma unroll
+            for (int k = 0; k < NN; k += 2) {
+                const double2 f2 = *reinterpret_cast<const double2*>(frow + k);
+                const double2 x2 = *reinterpret_cast<const double2*>(xnv + k);
+                acc = fma(-f2.x, x2.x, acc);
+                acc = fma(-f2.y, x2.y, acc);
+            }
+            xbv[j] = acc;
+        }
+        wcqp::wave_lds_fence();
+        nu0 = free0 ? xnv[kap0] : xbv[myrow0];
+        nu1 = var1 ? (free1 ? xnv[kap1] : xbv[myrow1]) : 0.0;
+    }
+    wcqp::wave_lds_fence();
+
+    WCQP_STAMP(7);
+    // ---------------- phase 5: joint-velocity bounds (qpOASES form) --------------------------------
+    int st_code = ok ? WCQP_STATUS_SOLVED : WCQP_STATUS_NUMERIC;
+    int it = 0;
+    bool in_w0 = false, in_w1 = false;
+    double sig0 = 0.0, sig1 = 0.0;
+    const double tol = prm->tol;
+    const bool bnd0 = j >= 6;                             // the base (columns 0..5) is unbounded
+    const bool bnd1 = var1;
+    double lo0 = prm->vlo[j], hi0 = prm->vhi[j], lo1 = prm->vlo[col1], hi1 = prm->vhi[col1];
+    lo0 = bnd0 ? lo0 : -inf; hi0 = bnd0 ? hi0 : inf;
+    lo1 = bnd1 ? lo1 : -inf; hi1 = bnd1 ? hi1 : inf;
+    const bool need = !osqp_form && ((bnd0 && fmax(nu0 - hi0, lo0 - nu0) > tol) || (bnd1 && fmax(nu1 - hi1, lo1 - nu1) > tol));
+    const unsigned long long need_m = __ballot(need);
+    if (((need_m >> (16 * grp)) & 0xffffull) != 0ull && st_code == WCQP_STATUS_SOLVED) {
+        // Goldfarb-Idnani dual active set as in ik_common.h (gi_active_set), two variables per lane:
+        // slot a of the working set is owned by lane a; all control flow is uniform inside a DPP row.
+        double* Rinv = S + OFF_RINV;
+        double* tpb = S + OFF_TPB;
+        double* zb = S + OFF_ZB;
+        double* sv = S + OFF_SV;
+        double* rvec = S + OFF_RV;
+        double* cvec = S + OFF_CV;
+        double* tkb = S + OFF_TKB;
+        double* tbv = S + OFF_TBV;
+        int* Wi = reinterpret_cast<int*>(S + OFF_WI);
+        int* info = reinterpret_cast<int*>(S + OFF_INFO);
+        bool s_live = false;
+        int s_var = 0;
+        double s_sg = 0.0, s_mu = 0.0;
+        double tc0[KMAX], tc1[KMAX];
+#pragma unroll
+        for (int a = 0; a < KMAX; ++a) { tc0[a] = 0.0; tc1[a] = 0.0; }
+        int nW = 0, hiW = 0;
+        if (j < KMAX) {
+            for (int b = 0; b < KMAX; ++b) Rinv[j * LDR + b] = 0.0;
+        }
+        wcqp::wave_lds_fence();
+        bool running = true;
+        const int max_iter = prm->max_iter;
+        while (running) {
+            // most violated bound outside the working set (choice on float keys, value read back exactly)
+            const double vh0 = nu0 - hi0, vl0 = lo0 - nu0, vh1 = nu1 - hi1, vl1 = lo1 - nu1;
+            const double viol0 = (bnd0 && !in_w0) ? fmax(vh0, vl0) : -inf;
+            const double viol1 = (bnd1 && !in_w1) ? fmax(vh1, vl1) : -inf;
+            const unsigned k0 = viol0 > tol ? (mag_key(viol0) | (unsigned)(31 - j)) : 0u;
+            const unsigned k1 = viol1 > tol ? (mag_key(viol1) | (unsigned)(15 - j)) : 0u;
+            const unsigned key = row_max_u32(max(k0, k1));
+            if (key == 0u) break;
+            if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; break; }
+            ++it;
+            const int p = 31 - (int)(key & 31u);
+            if (p == j) { sv[0] = viol0; sv[1] = vh0 >= vl0 ? 1.0 : -1.0; info[0] = free0 ? 0 : 1; info[1] = free0 ? kap0 : myrow0; }
+            if (p == col1) { sv[0] = viol1; sv[1] = vh1 >= vl1 ? 1.0 : -1.0; info[0] = free1 ? 0 : 1; info[1] = free1 ? kap1 : myrow1; }
+            wcqp::wave_lds_fence();
+            double s = sv[0];
+            const double sig = sv[1];
+            const bool p_basic = info[0] != 0;
+            const int p_idx = info[1];
+            // tau_p = Z Hr^-1 Z' e_p: t over the compact indices first, then the basic rows through F
+            {
+                if (!p_basic && j == p_idx) {
+#pragma unroll
+                    for (int k = 0; k < NN; ++k) tkb[k] = -Hr[k];          // row == column (symmetric)
+                }
+                double t = 0.0;
+                if (p_basic) {
+                    const double* frow = F + p_idx * 16;
+#pragma unroll
+                    for (int k = 0; k < NN; k += 2) {
+                        const double2 f2 = *reinterpret_cast<const double2*>(frow + k);
+                        t = fma(Hr[k], f2.x, t);
+                        t = fma(Hr[k + 1], f2.y, t);
+                    }
+                    wcqp::wave_lds_fence();
+                    tkb[j] = t;                                              // -Hinv F[row_p,:]'  (lanes >= NN: 0)
+                }
+                wcqp::wave_lds_fence();
+                const double* frow = F + (j < MEQ ? j : 0) * 16;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NN; k += 2) {
+                    const double2 f2 = *reinterpret_cast<const double2*>(frow + k);
+                    const double2 t2 = *reinterpret_cast<const double2*>(tkb + k);
+                    acc = fma(-f2.x, t2.x, acc);
+                    acc = fma(-f2.y, t2.y, acc);
+                }
+                tbv[j] = acc;
+                wcqp::wave_lds_fence();
+            }
+            const double tp0 = sig * (free0 ? tkb[kap0] : tbv[myrow0]);
+            const double tp1 = var1 ? sig * (free1 ? tkb[kap1] : tbv[myrow1]) : 0.0;
+            tpb[j] = tp0; tpb[col1] = tp1;
+            wcqp::wave_lds_fence();
+            const double ppp = sig * tpb[p];                 // P[p][p] > 0
+            double mu_p = 0.0;
+#pragma unroll 1
+            for (int inner = 0; inner <= KMAX + 1; ++inner) {
+                // dual step r = Rinv c,  c_a = sigma_a tp[w_a]
+                const double c_a = s_live ? s_sg * tpb[s_var] : 0.0;
+                cvec[j] = c_a;
+                wcqp::wave_lds_fence();
+                double r_a = 0.0;
+                if (s_live) {
+#pragma unroll 1
+                    for (int b = 0; b < hiW; ++b) r_a = fma(Rinv[j * LDR + b], cvec[b], r_a);
+                }
+                rvec[j] = r_a;
+                wcqp::wave_lds_fence();
+                // primal step z = tp - sum_a r_a Tc[a]
+                double z0 = tp0, z1 = tp1;
+#pragma unroll
+                for (int a = 0; a < KMAX; a += 2) {
+                    const double2 r2 = *reinterpret_cast<const double2*>(rvec + a);
+                    z0 = fma(-r2.x, tc0[a], z0); z1 = fma(-r2.x, tc1[a], z1);
+                    z0 = fma(-r2.y, tc0[a + 1], z0); z1 = fma(-r2.y, tc1[a + 1], z1);
+                }
+                zb[j] = z0; zb[col1] = z1;
+                wcqp::wave_lds_fence();
+                const double nzv = sig * zb[p];              // Schur complement of the bordered system
+                const double t2 = (nW < KMAX && nzv > 1e-10 * ppp) ? s / nzv : inf;
+                const double ratio = (s_live && r_a > 0.0) ? s_mu / r_a : inf;
+                const double t1 = row_min(ratio);
+                const double t = fmin(t1, t2);
+                if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; running = false; break; }
+                nu0 = fma(-t, z0, nu0);
+                nu1 = fma(-t, z1, nu1);
+                s_mu = s_live ? s_mu - t * r_a : s_mu;
+                mu_p += t;
+                s -= t * nzv;
+                if (t2 <= t1) {
+                    // full step: p enters the first free slot; Rinv <- bordered inverse
+                    const unsigned fm = (unsigned)((__ballot(j < KMAX && !s_live) >> (16 * grp)) & 0xffffull);
+                    const int n = fm ? __ffs(fm) - 1 : 0;
+                    const double inz = 1.0 / nzv;
+                    if (s_live) {
+#pragma unroll 1
+                        for (int b = 0; b < hiW; ++b) Rinv[j * LDR + b] = fma(r_a * inz, rvec[b], Rinv[j * LDR + b]);
+                        Rinv[j * LDR + n] = -r_a * inz;
+                    }
+                    wcqp::wave_lds_fence();
+                    if (j == n) {
+#pragma unroll 1
+                        for (int b = 0; b < KMAX; ++b) Rinv[n * LDR + b] = (b < hiW) ? -rvec[b] * inz : 0.0;
+                        Rinv[n * LDR + n] = inz;
+                        s_live = true; s_var = p; s_sg = sig; s_mu = mu_p;
+                        Wi[n] = p;
+                    }
+#pragma unroll
+                    for (int a = 0; a < KMAX; ++a) { tc0[a] = (a == n) ? tp0 : tc0[a]; tc1[a] = (a == n) ? tp1 : tc1[a]; }
+                    if (p == j) { in_w0 = true; sig0 = sig; }
+                    if (p == col1) { in_w1 = true; sig1 = sig; }
+                    ++nW;
+                    hiW = hiW > n + 1 ? hiW : n + 1;
+                    wcqp::wave_lds_fence();
+                    break;
+                }
+                // partial step: the blocking constraint leaves the working set; Rinv <- downdated inverse
+                const unsigned dm = (unsigned)((__ballot(ratio == t1) >> (16 * grp)) & 0xffffull);
+                const int jd = dm ? __ffs(dm) - 1 : 0;
+                const int wdrop = Wi[jd];
+                const double djj = Rinv[jd * LDR + jd];
+                if (s_live && j != jd) {
+                    const double f = Rinv[j * LDR + jd] / djj;
+#pragma unroll 1
+                    for (int b = 0; b < hiW; ++b) Rinv[j * LDR + b] = fma(-f, Rinv[jd * LDR + b], Rinv[j * LDR + b]);
+                }
+                wcqp::wave_lds_fence();
+                if (j < KMAX) Rinv[j * LDR + jd] = 0.0;
+                if (j == jd) {
+#pragma unroll 1
+                    for (int b = 0; b < KMAX; ++b) Rinv[jd * LDR + b] = 0.0;
+                    s_live = false; s_mu = 0.0;
+                }
+                if (wdrop == j) { in_w0 = false; sig0 = 0.0; }
+                if (wdrop == col1) { in_w1 = false; sig1 = 0.0; }
+                --nW;
+                ++it;
+                wcqp::wave_lds_fence();
+            }
+            wcqp::wave_lds_fence();
+        }
+        // certificate: every bound holds and every active bound is tight, else the walk lost accuracy
+        {
+            const double d0 = !bnd0 ? 0.0 : (in_w0 ? fabs(nu0 - (sig0 > 0.0 ? hi0 : lo0)) : fmax(nu0 - hi0, lo0 - nu0));
+            const double d1 = !bnd1 ? 0.0 : (in_w1 ? fabs(nu1 - (sig1 > 0.0 ? hi1 : lo1)) : fmax(nu1 - hi1, lo1 - nu1));
+            const double dev = fmax(d0 == d0 ? d0 : inf, d1 == d1 ? d1 : inf);
+            const double worst = row_max(dev);
+            if (st_code == WCQP_STATUS_SOLVED && worst > 1e-9) st_code = WCQP_STATUS_NUMERIC;
+            if (st_code == WCQP_STATUS_SOLVED && in_w0) nu0 = sig0 > 0.0 ? hi0 : lo0;
+            if (st_code == WCQP_STATUS_SOLVED && in_w1) nu1 = sig1 > 0.0 ? hi1 : lo1;
+        }
+    }
+
+    WCQP_STAMP(8);
+    // ---------------- outputs ------------------------------------------------------------------------
+    const unsigned long long bu0 = __ballot(in_w0 && sig0 > 0.0), bu1 = __ballot(in_w1 && sig1 > 0.0);
+    const unsigned long long bl0 = __ballot(in_w0 && sig0 < 0.0), bl1 = __ballot(in_w1 && sig1 < 0.0);
+    if (live) {
+        if (j >= 6) dq_out[inst * kDof + (j - 6)] = nu0;
+        if (var1) dq_out[inst * kDof + (j + 10)] = nu1;
+        if (j == 0) {
+            const unsigned up = (unsigned)((bu0 >> (16 * grp)) & 0xffffull) | ((unsigned)((bu1 >> (16 * grp)) & 0xffffull) << 16);
+            const unsigned dn = (unsigned)((bl0 >> (16 * grp)) & 0xffffull) | ((unsigned)((bl1 >> (16 * grp)) & 0xffffull) << 16);
+            status_out[inst] = st_code;
+            if (aup_out) aup_out[inst] = up >> 6;
+            if (alo_out) alo_out[inst] = dn >> 6;
+            if (iters_out) iters_out[inst] = it;
+        }
+    }
+#ifdef WCQP_IK_STAMPS
+    WCQP_STAMP(9);
+    return;
+#endif
+    if (ferr_out) {
+        double* nub = S + OFF_P;
+        wcqp::wave_lds_fence();
+        nub[j] = nu0;
+        nub[col1] = var1 ? nu1 : 0.0;
+        wcqp::wave_lds_fence();
+        if (j < 12 && live) {
+            const double* jrow = (j < 6 ? JL + inst * (6 * kNV) + j * kNV : JR + inst * (6 * kNV) + (j - 6) * kNV);
+            double acc = bvec[j];
+            for (int k = 0; k < kNV; ++k) acc = fma(-jrow[k], nub[k], acc);
+            ferr_out[inst * 12 + j] = acc;           // b - J nu (osqp.cpp:430-454, qp.cpp:364-401)
+        }
+    }
+}
+
+}  // namespace
+
+namespace wcqp_ik {
+
+int ik3_launch(const IkDeviceParams* d_prm, int batch,
+               const double* JL, const double* JR, const double* JN, const double* JC,
+               const double* q, const double* state, double* dq, int* status,
+               unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
+    const unsigned grid = (unsigned)((batch + 3) / 4);
+    hipLaunchKernelGGL(ik3_kernel, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+                       dq, status, alo, aup, ferr, iters);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+}  // namespace wcqp_ik

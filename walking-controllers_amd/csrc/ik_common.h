@@ -54,36 +54,65 @@ __device__ __forceinline__ double dpp_move(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// Row exchange inside a 32-lane group: v_permlane16_swap (new on gfx950) swaps the odd 16-lane rows
+// of one operand with the even rows of the other, so with both operands equal the two results hold
+// {own row, other row} in some order — a plain VALU op where ds_swizzle xor 16 is an LDS-pipe round trip.
+__device__ __forceinline__ unsigned rows_max_u32(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return max((unsigned)r[0], (unsigned)r[1]);
+}
+__device__ __forceinline__ void rows_pair(double v, double& d0, double& d1) {
+    const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    d0 = __hiloint2double((int)rh[0], (int)rl[0]);
+    d1 = __hiloint2double((int)rh[1], (int)rl[1]);
+}
 // all-reduce over the 32 lanes of a group: four DPP steps inside each row of 16 (xor 1, xor 2 as
 // quad permutes; then half-mirror and mirror, which pair up quads / octets that already agree),
-// one crossbar swap between the two rows
+// one row exchange between the two rows
 __device__ __forceinline__ double group_max(double v) {
     v = fmax(v, dpp_move<0xB1>(v));     // quad_perm [1,0,3,2]
     v = fmax(v, dpp_move<0x4E>(v));     // quad_perm [2,3,0,1]
     v = fmax(v, dpp_move<0x141>(v));    // row_half_mirror
     v = fmax(v, dpp_move<0x140>(v));    // row_mirror
-    v = fmax(v, group_xor<16>(v));
-    return v;
+    double d0, d1;
+    rows_pair(v, d0, d1);
+    return fmax(d0, d1);
 }
 __device__ __forceinline__ double group_min(double v) {
     v = fmin(v, dpp_move<0xB1>(v));
     v = fmin(v, dpp_move<0x4E>(v));
     v = fmin(v, dpp_move<0x141>(v));
     v = fmin(v, dpp_move<0x140>(v));
-    v = fmin(v, group_xor<16>(v));
-    return v;
+    double d0, d1;
+    rows_pair(v, d0, d1);
+    return fmin(d0, d1);
 }
 // Lane of the largest |v| among the candidate lanes of a 32-lane group (ties: lowest lane).
 // Pivot choice only needs the magnitude to float precision, so the search runs on a 32-bit key
 // (float bits with 31 - lane in the low 5) and each butterfly step is ONE DPP-fused v_max_u32.
-__device__ __forceinline__ int group_argmax_abs(double v, bool candidate, int i) {
+// `key_out` = the winning key (0 when there is no candidate); its upper 27 bits are |v| as a float.
+__device__ __forceinline__ int group_argmax_abs(double v, bool candidate, int i, unsigned& key_out) {
     unsigned key = candidate ? ((__float_as_uint((float)fabs(v)) & ~31u) | (unsigned)(31 - i)) : 0u;
     key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));
     key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));
     key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x141, 0xf, 0xf, false));
     key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x140, 0xf, 0xf, false));
-    key = max(key, (unsigned)__builtin_amdgcn_ds_swizzle((int)key, 0x1f | (16 << 10)));
+    key = rows_max_u32(key);
+    key_out = key;
     return 31 - (int)(key & 31u);
+}
+// value of `v` in wave lane `src` (wave-uniform): two v_readlane, result lives in SGPRs
+__device__ __forceinline__ double lane_value(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// value of `v` in wave lane `src_byte / 4` (ds_bpermute: through the LDS crossbar, no LDS memory,
+// one trip instead of the write -> wait -> read of a published column)
+__device__ __forceinline__ double lane_gather(double v, int src_byte) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_byte, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_byte, __double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
 // lowest lane of this 32-lane group whose predicate holds (32 if none)
@@ -244,6 +273,12 @@ __device__ __forceinline__ void gi_active_set(const GiScratch& w, int i, int hal
 
 // launch of the null-space kernel (ik2.hip)
 int ik2_launch(const IkDeviceParams* d_prm, bool use_com, bool use_mfma, int batch,
+               const double* JL, const double* JR, const double* JN, const double* JC,
+               const double* q, const double* state, double* dq, int* status,
+               unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream);
+
+// launch of the 16-lanes-per-instance null-space kernel (ik3.hip; CoM-as-constraint form only)
+int ik3_launch(const IkDeviceParams* d_prm, int batch,
                const double* JL, const double* JR, const double* JN, const double* JC,
                const double* q, const double* state, double* dq, int* status,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream);

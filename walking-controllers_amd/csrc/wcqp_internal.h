@@ -58,6 +58,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 // through an empty volatile asm with a memory clobber pins both: the reads cannot cross it and
 // the chain has to finish in front of it.
 __device__ __forceinline__ void pin_result(double& x) { __asm__ volatile("" : "+v"(x) :: "memory"); }
+// Same for a 32-bit value, without the memory clobber: makes hipcc materialise `x` HERE instead of
+// keeping everything it was computed from alive to rebuild it later (it otherwise carries the 15
+// pivot keys of the Gauss-Jordan through the whole elimination to derive each lane's row at the end).
+__device__ __forceinline__ void pin_value(int& x) { __asm__ volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin_value(unsigned& x) { __asm__ volatile("" : "+v"(x)); }
 
 // 1/x: v_rcp_f64 seed + two Newton steps (error <= ~1 ulp; the QPs need 1e-9, not
 // correctly-rounded division, and the IEEE division sequence is ~3x longer).
