@@ -1,11 +1,13 @@
 #!/bin/bash
-# Diagnostic only: builds libwcqp variants that differ in the flags given to ik2.hip
+# Diagnostic only: builds libwcqp variants that differ in the flags given to the IK kernels
 #   tools/build_variant.sh NAME [-Dflag ...]   ->  walking-controllers_amd/csrc/build/diag/libwcqp_NAME.so
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../walking-controllers_amd/csrc"
 make -s >/dev/null
 mkdir -p build/diag
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. "$@" -x hip -c ik2.hip -o build/diag/ik2_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/diag/libwcqp_$name.so build/common.cpp.o build/mpc.hip.o build/ik.hip.o build/diag/ik2_$name.o build/tick.hip.o build/hull.hip.o build/host_WalkingControllers.o
+for f in ik2 ik3; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. "$@" -x hip -c $f.hip -o build/diag/${f}_$name.o
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/diag/libwcqp_$name.so build/common.cpp.o build/mpc.hip.o build/ik.hip.o build/diag/ik2_$name.o build/diag/ik3_$name.o build/tick.hip.o build/hull.hip.o build/host_WalkingControllers.o
 echo built build/diag/libwcqp_$name.so

@@ -9,9 +9,10 @@ dev = torch.device("cuda", 0)
 ib = wca.synth.synth_ik_batch(B, seed=4321)
 d = {k: torch.from_numpy(ib[k]).to(dev) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")}
 dq = torch.zeros(B, 23, dtype=torch.float64, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
-nw = (B + 1) // 2
+alg = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+nw = (B + 3) // 4 if alg == 4 else (B + 1) // 2
 dbg = torch.zeros(nw * 16, dtype=torch.int64, device=dev)
-ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=int(sys.argv[3]) if len(sys.argv) > 3 else 3)
+ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=alg)
 sp = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     ik.solve_device(B, d["J_left"].data_ptr(), d["J_right"].data_ptr(), d["J_neck"].data_ptr(), d["J_com"].data_ptr(), d["q"].data_ptr(), d["state"].data_ptr(), dq.data_ptr(), st.data_ptr(), 0, 0, dbg.data_ptr(), 0, sp)
@@ -20,7 +21,7 @@ t = dbg.cpu().numpy().reshape(nw, 16)[:, :10].astype(np.float64)
 seg = np.diff(t, axis=1)
 names = ["loads", "rhs+grad", "gauss-jordan", "rows->tables", "Hr build", "sweep", "x_N,x_B", "active set", "outputs"]
 full = dbg.cpu().numpy().reshape(nw, 16).astype(np.float64)
-gj = {"panel0 (4 steps + trailing)": float(np.median(full[:, 14] - full[:, 2])),
+gj = {"gi: init": float(np.median(full[:, 10] - full[:, 7])), "first bound (straight-line)": float(np.median(full[:, 14] - full[:, 10])), "general loop": float(np.median(full[:, 15] - full[:, 14])), "cert+rest": float(np.median(full[:, 8] - full[:, 15]))} if alg == 4 else {"panel0 (4 steps + trailing)": float(np.median(full[:, 14] - full[:, 2])),
       "panel1 step0": float(np.median(full[:, 10] - full[:, 14])), "panel1 step1": float(np.median(full[:, 11] - full[:, 10])),
       "panel1 step2": float(np.median(full[:, 12] - full[:, 11])), "panel1 step3": float(np.median(full[:, 13] - full[:, 12])),
       "panel1 trailing": float(np.median(full[:, 15] - full[:, 13]))}

@@ -25,15 +25,20 @@ constexpr int MEQ = 15;               // equality rows (CoM as constraint)
 constexpr int NCOST = 3;              // cost rows: J_neck
 constexpr int NN = kNV - MEQ;         // 14 free variables
 constexpr int KMAX = NN;
-constexpr int LDR = KMAX | 1;         // 15
+constexpr int LDR = KMAX | 1;         // 15: odd, row-per-lane b64 accesses spread over the banks
 constexpr int LDH = 18;
 
 // ---- LDS layout per instance (doubles) ---------------------------------------------------------
-constexpr int OFF_F = 0;              // [15][16]  F[r][k] = (A_B^-1 A_N)[r][k], column NN = b'
-constexpr int OFF_P = 240;
+// Leading dimensions of 18 doubles make the row-per-lane b128 reads (lane j reads row j) conflict
+// free: 36 j mod 64 are 16 distinct multiples of 4 banks.  PER_INST = 24 mod 32 doubles puts the
+// four instances of a wave 16 banks apart, so a broadcast read that serves two instances in one
+// lane group does not collide either (at a multiple of 32 doubles every such read was 2-way).
+constexpr int LDF = 18;
+constexpr int OFF_F = 0;              // [15][LDF]  F[r][k] = (A_B^-1 A_N)[r][k], column NN = b'
+constexpr int OFF_P = 15 * LDF;       // 270
 //   set-up
 constexpr int OFF_ST = OFF_P;         // [112] state + q (dead after the gradient)
-constexpr int OFF_CB = OFF_P + 112;   // [4][16] entries of a panel's 4 pivot columns
+constexpr int OFF_CB = OFF_P + 112;   // [4][16] entries of a panel's 4 pivot columns; before that the task rhs b
 constexpr int OFF_RD = OFF_P + 176;   // [16][8] per row r: {D, g, neck-row entries} of its basic variable
 constexpr int OFF_GRV = OFF_P + 304;  // [16] reduced gradient by compact index
 constexpr int OFF_DN = OFF_P + 320;   // [16] Lambda entry of the free variable with compact index k
@@ -46,22 +51,23 @@ constexpr int OFF_XBV = OFF_P + 48;   // [16] x_B by row
 //   active set (over the set-up area)
 constexpr int OFF_RINV = OFF_P;       // [KMAX][LDR]
 constexpr int OFF_TPB = OFF_P + 212;  // [32] column tau_p by variable
-constexpr int OFF_ZB = OFF_P + 244;   // [32] sign / primal step by variable
-constexpr int OFF_SV = OFF_P + 276;   // [32] violation by variable
-constexpr int OFF_RV = OFF_P + 308;   // [16] dual step per slot
-constexpr int OFF_CV = OFF_P + 324;   // [16]
-constexpr int OFF_TKB = OFF_P + 340;  // [16] t by compact index
-constexpr int OFF_TBV = OFF_P + 356;  // [16] -F t by row
-constexpr int OFF_WI = OFF_P + 372;   // [16] ints: variable of slot a
-constexpr int OFF_INFO = OFF_P + 380; // [4]
-constexpr int OFF_B = OFF_P + 384;    // [16] task rhs (kept for the foot errors)
-constexpr int PER_INST = OFF_B + 16;  // 640
-static_assert(OFF_DN + 16 <= OFF_B && OFF_INFO + 4 <= OFF_B && OFF_HM + 16 * LDH <= OFF_GRV, "LDS overlays");
+constexpr int OFF_ZB = OFF_P + 244;   // [32] primal step by variable
+constexpr int OFF_RV = OFF_P + 276;   // [16] dual step per slot
+constexpr int OFF_CV = OFF_P + 292;   // [16]
+constexpr int OFF_TKB = OFF_P + 308;  // [16] t by compact index
+constexpr int OFF_TBV = OFF_P + 324;  // [16] -F t by row
+constexpr int OFF_WI = OFF_P + 340;   // [16] ints: variable of slot a
+constexpr int OFF_INFO = OFF_P + 348; // [4] ints
+constexpr int OFF_SV = OFF_P + 350;   // [2] violation and sign of the entering bound
+constexpr int P_SIZE = 352;
+constexpr int PER_INST = 632;         // >= OFF_P + P_SIZE = 622, = 24 mod 32
+static_assert(OFF_DN + 16 <= OFF_P + P_SIZE && OFF_HM + 16 * LDH <= OFF_GRV && OFF_P + P_SIZE <= PER_INST, "LDS overlays");
+static_assert(PER_INST % 32 == 24 || PER_INST % 32 == 8, "instances 16 banks apart");
 static_assert(PER_INST * 8 * 4 * 8 <= 160 * 1024, "8 blocks per CU");
 
 #ifdef WCQP_IK_STAMPS
 #define WCQP_STAMP(k) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
-                           if (lane == 0) reinterpret_cast<unsigned long long*>(ferr_out)[(size_t)blockIdx.x * 16 + (k)] = t__; } while (0)
+                           if (lane == __ffsll((long long)__ballot(true)) - 1) reinterpret_cast<unsigned long long*>(ferr_out)[(size_t)blockIdx.x * 16 + (k)] = t__; } while (0)
 #else
 #define WCQP_STAMP(k) do { } while (0)
 #endif
@@ -110,7 +116,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     double* S = smem[grp];
     double* F = S + OFF_F;
     double* st = S + OFF_ST;
-    double* bvec = S + OFF_B;
+    double* bvec = S + OFF_CB;       // task rhs, handed to the rhs column before the elimination starts
     const double inf = std::numeric_limits<double>::infinity();
     const bool var1 = j < kNV - 16;                 // column j + 16 is a variable (j < 13)
     const bool rhs1 = j == kNV - 16;                // column 29 = b
@@ -122,11 +128,22 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     double a0[MEQ], a1[MEQ];    // columns j and j + 16 of A = [J_left; J_right; J_com]; lane 13 slot 1: b
     double cn0[NCOST], cn1[NCOST];
     {
+        // the state block first: vmcnt retires in order, and the rhs / gradient phase only needs the
+        // state, q and the neck rows, so the 30 Jacobian loads stay in flight underneath it
+        const double* sp = state + inst * kStateLen;
+        double sreg[6];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
+        sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
+        const double q0 = qpos[inst * kDof + j];
+        const double q1 = qpos[inst * kDof + (16 + j < kDof ? 16 + j : 0)];
         const int c1 = var1 ? col1 : kNV - 1;       // lanes 13..15 reload column 28 (never used)
         const double* jl = JL + inst * (6 * kNV);
         const double* jr = JR + inst * (6 * kNV);
         const double* jc = JC + inst * (3 * kNV);
         const double* jn = JN + inst * (3 * kNV);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cn0[r] = jn[r * kNV + j]; cn1[r] = jn[r * kNV + c1]; }
 #pragma unroll
         for (int r = 0; r < 6; ++r) { a0[r] = jl[r * kNV + j]; a1[r] = jl[r * kNV + c1]; }
 #pragma unroll
@@ -134,21 +151,18 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
         for (int r = 0; r < 3; ++r) { a0[12 + r] = jc[r * kNV + j]; a1[12 + r] = jc[r * kNV + c1]; }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { cn0[r] = jn[r * kNV + j]; cn1[r] = jn[r * kNV + c1]; }
-        const double* sp = state + inst * kStateLen;
-#pragma unroll
-        for (int m = 0; m < 5; ++m) st[m * 16 + j] = sp[m * 16 + j];
-        if (80 + j < kStateLen) st[80 + j] = sp[80 + j];
-        st[kStateLen + j] = qpos[inst * kDof + j];
-        if (16 + j < kDof) st[kStateLen + 16 + j] = qpos[inst * kDof + 16 + j];
+        for (int m = 0; m < 5; ++m) st[m * 16 + j] = sreg[m];
+        if (80 + j < kStateLen) st[80 + j] = sreg[5];
+        st[kStateLen + j] = q0;
+        if (16 + j < kDof) st[kStateLen + 16 + j] = q1;
     }
     wcqp::wave_lds_fence();
 
     WCQP_STAMP(1);
     // ---------------- phase 1: task rhs b (lane r < MEQ) and gradient g ---------------------------
     const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
+    double b_mine = 0.0;
     if (j < MEQ) {
-        double b_mine;
         if (j < 12) {
             const int foot = j / 6, k = j % 6;
             const double* p  = st + (foot ? 12 : 0);
@@ -193,6 +207,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     {
         double* cb = S + OFF_CB;
         const int rowbase = lane & 48;
+        const unsigned var1_mask = var1 ? 0xffffffffu : 0u;
 #pragma unroll
         for (int r0 = 0; r0 < MEQ; r0 += 4) {
             const int pw = (MEQ - r0 < 4) ? MEQ - r0 : 4;
@@ -200,8 +215,9 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             for (int s = 0; s < pw; ++s) {
                 const int r = r0 + s;
                 // this lane's better candidate; its panel entries are what the lane would publish
-                const unsigned k0 = (myrow0 < 0) ? (mag_key(a0[r]) | (unsigned)(31 - j)) : 0u;
-                const unsigned k1 = (var1 && myrow1 < 0) ? (mag_key(a1[r]) | (unsigned)(15 - j)) : 0u;
+                // (arithmetic masks, not selects: hipcc turns a select around the float conversion into a branch)
+                const unsigned k0 = (mag_key(a0[r]) | (unsigned)(31 - j)) & (unsigned)(myrow0 >> 31);
+                const unsigned k1 = (mag_key(a1[r]) | (unsigned)(15 - j)) & (unsigned)(myrow1 >> 31) & var1_mask;
                 const bool best1 = k1 > k0;
                 double m[4];
 #pragma unroll
@@ -212,9 +228,11 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const int p = 31 - (int)(key & 31u);    // pivot column
                 myrow0 = (p == j) ? r : myrow0;
                 myrow1 = (p == col1) ? r : myrow1;
+#ifndef WCQP_IK3_NOPIN
                 wcqp::pin_value(kmin);
                 wcqp::pin_value(myrow0);
                 wcqp::pin_value(myrow1);
+#endif
                 const int src = (rowbase + (p & 15)) << 2;
                 double c[4];
 #pragma unroll
@@ -226,21 +244,28 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 }
                 a0[r] = t0; a1[r] = t1;
             }
-            // rank-pw update of the other rows; the pivot lanes publish their untouched entries of those rows
-            if (myrow0 >= r0) {
-                double* c = cb + (myrow0 - r0) * 16;
+            // rank-pw update of the other rows; the pivot lanes publish their untouched entries of those
+            // rows.  A store costs per instruction, so both slots share one sequence (a lane that holds
+            // two pivots of the same panel is rare and gets a second one).
+            {
+                const bool piv0 = myrow0 >= r0, piv1 = myrow1 >= r0;
+                if (piv0 || piv1) {
+                    double* c = cb + ((piv0 ? myrow0 : myrow1) - r0) * 16;
 #pragma unroll
-                for (int q = 0; q < MEQ; q += 2) {
-                    if (q >= r0 && q < r0 + 4) continue;
-                    *reinterpret_cast<double2*>(c + q) = make_double2(a0[q], q + 1 < MEQ ? a0[q + 1] : 0.0);
+                    for (int q = 0; q < MEQ; q += 2) {
+                        if (q >= r0 && q < r0 + 4) continue;
+                        *reinterpret_cast<double2*>(c + q) = make_double2(piv0 ? a0[q] : a1[q], q + 1 < MEQ ? (piv0 ? a0[q + 1] : a1[q + 1]) : 0.0);
+                    }
                 }
-            }
-            if (myrow1 >= r0) {
-                double* c = cb + (myrow1 - r0) * 16;
+                if (__ballot(piv0 && piv1) != 0ull) {
+                    if (piv0 && piv1) {
+                        double* c = cb + (myrow1 - r0) * 16;
 #pragma unroll
-                for (int q = 0; q < MEQ; q += 2) {
-                    if (q >= r0 && q < r0 + 4) continue;
-                    *reinterpret_cast<double2*>(c + q) = make_double2(a1[q], q + 1 < MEQ ? a1[q + 1] : 0.0);
+                        for (int q = 0; q < MEQ; q += 2) {
+                            if (q >= r0 && q < r0 + 4) continue;
+                            *reinterpret_cast<double2*>(c + q) = make_double2(a1[q], q + 1 < MEQ ? a1[q + 1] : 0.0);
+                        }
+                    }
                 }
             }
             wcqp::wave_lds_fence();
@@ -294,12 +319,12 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
     if (free0) {
 #pragma unroll
-        for (int r = 0; r < MEQ; ++r) F[r * 16 + kap0] = a0[r];
+        for (int r = 0; r < MEQ; ++r) F[r * LDF + kap0] = a0[r];
         S[OFF_DN + kap0] = Di0;
     }
     if (own1) {
 #pragma unroll
-        for (int r = 0; r < MEQ; ++r) F[r * 16 + kap1] = a1[r];
+        for (int r = 0; r < MEQ; ++r) F[r * LDF + kap1] = a1[r];
         S[OFF_DN + kap1] = Di1;
     }
     wcqp::wave_lds_fence();
@@ -343,7 +368,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         xtt[3 * 16 + j] = 0.0; xtt[4 * 16 + j] = 0.0;
         ytt[3 * 16 + j] = 0.0; ytt[4 * 16 + j] = 0.0;
         if (j < 3) { xtt[j * 16 + 15] = 0.0; ytt[j * 16 + 15] = 0.0; }
-        if (j < MEQ) F[j * 16 + 15] = 0.0;
+        if (j < MEQ) F[j * LDF + 15] = 0.0;
     }
     wcqp::wave_lds_fence();
 
@@ -360,8 +385,8 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         for (int s = 0; s < 5; ++s) {
             const int kk = 4 * s + mq;
             const bool tail = kk >= MEQ;
-            const int oy = tail ? OFF_YTT + (kk - MEQ) * 16 + mk : OFF_F + kk * 16 + mk;
-            const int ox = tail ? OFF_XTT + (kk - MEQ) * 16 + mk : OFF_F + kk * 16 + mk;
+            const int oy = tail ? OFF_YTT + (kk - MEQ) * 16 + mk : OFF_F + kk * LDF + mk;
+            const int ox = tail ? OFF_XTT + (kk - MEQ) * 16 + mk : OFF_F + kk * LDF + mk;
             const int od = tail ? OFF_RD : OFF_RD + kk * 8;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -392,6 +417,8 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     wcqp::wave_lds_fence();
 
     WCQP_STAMP(5);
+    // bounds: fetched here so that the (L2) latency hides under the sweep
+    double lo0 = prm->vlo[j], hi0 = prm->vhi[j], lo1 = prm->vlo[col1], hi1 = prm->vhi[col1];
     // ---------------- phase 4: Hr^-1 (sweep over the NN pivots), x_N, x_B -------------------------
     {
         double* col = S + OFF_COL;
@@ -439,7 +466,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         xnv[j] = xn;                                      // x_N = -Hinv g_r
         wcqp::wave_lds_fence();
         {
-            const double* frow = F + (j < MEQ ? j : 0) * 16;
+            const double* frow = F + (j < MEQ ? j : 0) * LDF;
             double acc = frow[NN];                        // b'
 #pragma unroll
             for (int k = 0; k < NN; k += 2) {
@@ -465,14 +492,18 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const double tol = prm->tol;
     const bool bnd0 = j >= 6;                             // the base (columns 0..5) is unbounded
     const bool bnd1 = var1;
-    double lo0 = prm->vlo[j], hi0 = prm->vhi[j], lo1 = prm->vlo[col1], hi1 = prm->vhi[col1];
     lo0 = bnd0 ? lo0 : -inf; hi0 = bnd0 ? hi0 : inf;
     lo1 = bnd1 ? lo1 : -inf; hi1 = bnd1 ? hi1 : inf;
     const bool need = !osqp_form && ((bnd0 && fmax(nu0 - hi0, lo0 - nu0) > tol) || (bnd1 && fmax(nu1 - hi1, lo1 - nu1) > tol));
     const unsigned long long need_m = __ballot(need);
     if (((need_m >> (16 * grp)) & 0xffffull) != 0ull && st_code == WCQP_STATUS_SOLVED) {
-        // Goldfarb-Idnani dual active set as in ik_common.h (gi_active_set), two variables per lane:
-        // slot a of the working set is owned by lane a; all control flow is uniform inside a DPP row.
+        // Goldfarb-Idnani dual active set as in ik_common.h (gi_active_set), two variables per lane.
+        // Slot a of the working set is owned by lane a; row a of the explicit inverse Rinv of the
+        // active-bound system sits in LDS (bordering on add, rank-one downdate on drop: registers
+        // are what this phase is short of).  ONE flat loop, one step per pass: a pass first picks
+        // the entering bound and its column tau_p if none is pending, then takes the primal/dual
+        // step.  All control flow is uniform inside a DPP row; an empty working set - by far the
+        // most common state when a bound enters - skips the dual-step machinery altogether.
         double* Rinv = S + OFF_RINV;
         double* tpb = S + OFF_TPB;
         double* zb = S + OFF_ZB;
@@ -487,54 +518,60 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         int s_var = 0;
         double s_sg = 0.0, s_mu = 0.0;
         double tc0[KMAX], tc1[KMAX];
-#pragma unroll
-        for (int a = 0; a < KMAX; ++a) { tc0[a] = 0.0; tc1[a] = 0.0; }
-        int nW = 0, hiW = 0;
-        if (j < KMAX) {
-            for (int b = 0; b < KMAX; ++b) Rinv[j * LDR + b] = 0.0;
-        }
-        wcqp::wave_lds_fence();
-        bool running = true;
+        double* myR = Rinv + (j < KMAX ? j : 0) * LDR;
+        int nW = 0;
         const int max_iter = prm->max_iter;
-        while (running) {
-            // most violated bound outside the working set (choice on float keys, value read back exactly)
-            const double vh0 = nu0 - hi0, vl0 = lo0 - nu0, vh1 = nu1 - hi1, vl1 = lo1 - nu1;
-            const double viol0 = (bnd0 && !in_w0) ? fmax(vh0, vl0) : -inf;
-            const double viol1 = (bnd1 && !in_w1) ? fmax(vh1, vl1) : -inf;
+        WCQP_STAMP(10);
+        // pending entering bound: variable p, sign, remaining violation s, column tau_p, P[p][p], multiplier
+        bool pending = false;
+        int p = 0;
+        double sig = 0.0, s = 0.0, tp0 = 0.0, tp1 = 0.0, ppp = 1.0, mu_p = 0.0;
+        bool done = false;
+        // key of the most violated bound outside the working set (0: none); the choice runs on float
+        // keys, the value itself is read back exactly from the owner
+        auto most_violated = [&]() -> unsigned {
+            const double viol0 = (bnd0 && !in_w0) ? fmax(nu0 - hi0, lo0 - nu0) : -inf;
+            const double viol1 = (bnd1 && !in_w1) ? fmax(nu1 - hi1, lo1 - nu1) : -inf;
             const unsigned k0 = viol0 > tol ? (mag_key(viol0) | (unsigned)(31 - j)) : 0u;
             const unsigned k1 = viol1 > tol ? (mag_key(viol1) | (unsigned)(15 - j)) : 0u;
-            const unsigned key = row_max_u32(max(k0, k1));
-            if (key == 0u) break;
-            if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; break; }
+            return row_max_u32(max(k0, k1));
+        };
+        // makes the bound of `key` the pending one: p, sig, s, tau_p = Z Hr^-1 Z' e_p (t over the
+        // compact indices first, then the basic rows through F), P[p][p]
+        auto enter = [&](unsigned key) {
             ++it;
-            const int p = 31 - (int)(key & 31u);
-            if (p == j) { sv[0] = viol0; sv[1] = vh0 >= vl0 ? 1.0 : -1.0; info[0] = free0 ? 0 : 1; info[1] = free0 ? kap0 : myrow0; }
-            if (p == col1) { sv[0] = viol1; sv[1] = vh1 >= vl1 ? 1.0 : -1.0; info[0] = free1 ? 0 : 1; info[1] = free1 ? kap1 : myrow1; }
+            p = 31 - (int)(key & 31u);
+            if (p == j) {
+                const double vh = nu0 - hi0, vl = lo0 - nu0;
+                sv[0] = fmax(vh, vl); sv[1] = vh >= vl ? 1.0 : -1.0; info[0] = free0 ? 0 : 1; info[1] = free0 ? kap0 : myrow0;
+            }
+            if (p == col1) {
+                const double vh = nu1 - hi1, vl = lo1 - nu1;
+                sv[0] = fmax(vh, vl); sv[1] = vh >= vl ? 1.0 : -1.0; info[0] = free1 ? 0 : 1; info[1] = free1 ? kap1 : myrow1;
+            }
             wcqp::wave_lds_fence();
-            double s = sv[0];
-            const double sig = sv[1];
+            s = sv[0];
+            sig = sv[1];
             const bool p_basic = info[0] != 0;
             const int p_idx = info[1];
-            // tau_p = Z Hr^-1 Z' e_p: t over the compact indices first, then the basic rows through F
-            {
-                if (!p_basic && j == p_idx) {
+            if (!p_basic && j == p_idx) {
 #pragma unroll
-                    for (int k = 0; k < NN; ++k) tkb[k] = -Hr[k];          // row == column (symmetric)
-                }
+                for (int k = 0; k < NN; k += 2) *reinterpret_cast<double2*>(tkb + k) = make_double2(-Hr[k], -Hr[k + 1]);   // row == column
+            }
+            if (p_basic) {
+                const double* frow = F + p_idx * LDF;
                 double t = 0.0;
-                if (p_basic) {
-                    const double* frow = F + p_idx * 16;
 #pragma unroll
-                    for (int k = 0; k < NN; k += 2) {
-                        const double2 f2 = *reinterpret_cast<const double2*>(frow + k);
-                        t = fma(Hr[k], f2.x, t);
-                        t = fma(Hr[k + 1], f2.y, t);
-                    }
-                    wcqp::wave_lds_fence();
-                    tkb[j] = t;                                              // -Hinv F[row_p,:]'  (lanes >= NN: 0)
+                for (int k = 0; k < NN; k += 2) {
+                    const double2 f2 = *reinterpret_cast<const double2*>(frow + k);
+                    t = fma(Hr[k], f2.x, t);
+                    t = fma(Hr[k + 1], f2.y, t);
                 }
-                wcqp::wave_lds_fence();
-                const double* frow = F + (j < MEQ ? j : 0) * 16;
+                tkb[j] = t;                                          // -Hinv F[row_p,:]'  (lanes >= NN: 0)
+            }
+            wcqp::wave_lds_fence();
+            {
+                const double* frow = F + (j < MEQ ? j : 0) * LDF;
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < NN; k += 2) {
@@ -544,107 +581,159 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                     acc = fma(-f2.y, t2.y, acc);
                 }
                 tbv[j] = acc;
-                wcqp::wave_lds_fence();
             }
-            const double tp0 = sig * (free0 ? tkb[kap0] : tbv[myrow0]);
-            const double tp1 = var1 ? sig * (free1 ? tkb[kap1] : tbv[myrow1]) : 0.0;
-            tpb[j] = tp0; tpb[col1] = tp1;
             wcqp::wave_lds_fence();
-            const double ppp = sig * tpb[p];                 // P[p][p] > 0
-            double mu_p = 0.0;
-#pragma unroll 1
-            for (int inner = 0; inner <= KMAX + 1; ++inner) {
-                // dual step r = Rinv c,  c_a = sigma_a tp[w_a]
-                const double c_a = s_live ? s_sg * tpb[s_var] : 0.0;
-                cvec[j] = c_a;
+            tp0 = sig * (free0 ? tkb[kap0] : tbv[myrow0]);
+            tp1 = var1 ? sig * (free1 ? tkb[kap1] : tbv[myrow1]) : 0.0;
+            ppp = p_basic ? tbv[p_idx] : tkb[p_idx];                 // P[p][p] > 0 (sig * sig * tau_p[p])
+            tpb[j] = tp0; tpb[col1] = tp1;                           // read by the slot lanes when nW > 0
+            mu_p = 0.0;
+            pending = true;
+        };
+        // First bound, empty working set, straight-line (no loop bookkeeping): full step along tau_p,
+        // the bound takes slot 0.  Three instances in four need nothing else.
+        {
+            const unsigned key = most_violated();          // != 0: that is what `need` said
+            enter(key);
+            if (ppp > 0.0) {
+                const double inz = wcqp::fast_rcp(ppp);
+                const double t = s * inz;
+                nu0 = fma(-t, tp0, nu0);
+                nu1 = fma(-t, tp1, nu1);
+                // (Rinv and the other slots' columns are only set up if the general loop is entered)
+                if (j == 0) { s_live = true; s_var = p; s_sg = sig; s_mu = t; Wi[0] = p; }
+                tc0[0] = tp0; tc1[0] = tp1;
+                ppp = inz;                                 // = Rinv[0][0], kept for that set-up
+                if (p == j) { in_w0 = true; sig0 = sig; }
+                if (p == col1) { in_w1 = true; sig1 = sig; }
+                nW = 1;
+                pending = false;
                 wcqp::wave_lds_fence();
-                double r_a = 0.0;
-                if (s_live) {
-#pragma unroll 1
-                    for (int b = 0; b < hiW; ++b) r_a = fma(Rinv[j * LDR + b], cvec[b], r_a);
-                }
-                rvec[j] = r_a;
-                wcqp::wave_lds_fence();
-                // primal step z = tp - sum_a r_a Tc[a]
-                double z0 = tp0, z1 = tp1;
+                done = most_violated() == 0u;
+            } else {
+                st_code = WCQP_STATUS_INFEASIBLE; done = true;
+            }
+        }
+        WCQP_STAMP(14);
+        if (!done) {
 #pragma unroll
-                for (int a = 0; a < KMAX; a += 2) {
-                    const double2 r2 = *reinterpret_cast<const double2*>(rvec + a);
-                    z0 = fma(-r2.x, tc0[a], z0); z1 = fma(-r2.x, tc1[a], z1);
-                    z0 = fma(-r2.y, tc0[a + 1], z0); z1 = fma(-r2.y, tc1[a + 1], z1);
-                }
-                zb[j] = z0; zb[col1] = z1;
-                wcqp::wave_lds_fence();
-                const double nzv = sig * zb[p];              // Schur complement of the bordered system
-                const double t2 = (nW < KMAX && nzv > 1e-10 * ppp) ? s / nzv : inf;
-                const double ratio = (s_live && r_a > 0.0) ? s_mu / r_a : inf;
-                const double t1 = row_min(ratio);
-                const double t = fmin(t1, t2);
-                if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; running = false; break; }
-                nu0 = fma(-t, z0, nu0);
-                nu1 = fma(-t, z1, nu1);
-                s_mu = s_live ? s_mu - t * r_a : s_mu;
-                mu_p += t;
-                s -= t * nzv;
-                if (t2 <= t1) {
-                    // full step: p enters the first free slot; Rinv <- bordered inverse
-                    const unsigned fm = (unsigned)((__ballot(j < KMAX && !s_live) >> (16 * grp)) & 0xffffull);
-                    const int n = fm ? __ffs(fm) - 1 : 0;
-                    const double inz = 1.0 / nzv;
-                    if (s_live) {
-#pragma unroll 1
-                        for (int b = 0; b < hiW; ++b) Rinv[j * LDR + b] = fma(r_a * inz, rvec[b], Rinv[j * LDR + b]);
-                        Rinv[j * LDR + n] = -r_a * inz;
-                    }
-                    wcqp::wave_lds_fence();
-                    if (j == n) {
-#pragma unroll 1
-                        for (int b = 0; b < KMAX; ++b) Rinv[n * LDR + b] = (b < hiW) ? -rvec[b] * inz : 0.0;
-                        Rinv[n * LDR + n] = inz;
-                        s_live = true; s_var = p; s_sg = sig; s_mu = mu_p;
-                        Wi[n] = p;
-                    }
+            for (int a = 1; a < KMAX; ++a) { tc0[a] = 0.0; tc1[a] = 0.0; }
+            if (j < KMAX) {
 #pragma unroll
-                    for (int a = 0; a < KMAX; ++a) { tc0[a] = (a == n) ? tp0 : tc0[a]; tc1[a] = (a == n) ? tp1 : tc1[a]; }
-                    if (p == j) { in_w0 = true; sig0 = sig; }
-                    if (p == col1) { in_w1 = true; sig1 = sig; }
-                    ++nW;
-                    hiW = hiW > n + 1 ? hiW : n + 1;
-                    wcqp::wave_lds_fence();
-                    break;
-                }
-                // partial step: the blocking constraint leaves the working set; Rinv <- downdated inverse
-                const unsigned dm = (unsigned)((__ballot(ratio == t1) >> (16 * grp)) & 0xffffull);
-                const int jd = dm ? __ffs(dm) - 1 : 0;
-                const int wdrop = Wi[jd];
-                const double djj = Rinv[jd * LDR + jd];
-                if (s_live && j != jd) {
-                    const double f = Rinv[j * LDR + jd] / djj;
-#pragma unroll 1
-                    for (int b = 0; b < hiW; ++b) Rinv[j * LDR + b] = fma(-f, Rinv[jd * LDR + b], Rinv[j * LDR + b]);
-                }
-                wcqp::wave_lds_fence();
-                if (j < KMAX) Rinv[j * LDR + jd] = 0.0;
-                if (j == jd) {
-#pragma unroll 1
-                    for (int b = 0; b < KMAX; ++b) Rinv[jd * LDR + b] = 0.0;
-                    s_live = false; s_mu = 0.0;
-                }
-                if (wdrop == j) { in_w0 = false; sig0 = 0.0; }
-                if (wdrop == col1) { in_w1 = false; sig1 = 0.0; }
-                --nW;
-                ++it;
-                wcqp::wave_lds_fence();
+                for (int b = 0; b < KMAX; ++b) myR[b] = (j == 0 && b == 0) ? ppp : 0.0;
             }
             wcqp::wave_lds_fence();
         }
+#pragma unroll 1
+        for (int pass = 0; pass < 1024 && !done; ++pass) {
+            if (!pending) {
+                const unsigned key = most_violated();
+                if (key == 0u) { done = true; }
+                else if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; }
+                else enter(key);
+            }
+            if (!done) {
+                double r_a = 0.0, z0 = tp0, z1 = tp1, nzv = ppp, t1 = inf, ratio = inf;
+                if (nW > 0) {
+                    // dual step r = Rinv c,  c_a = sigma_a tp[w_a]
+                    wcqp::wave_lds_fence();
+                    cvec[j] = s_live ? s_sg * tpb[s_var] : 0.0;
+                    wcqp::wave_lds_fence();
+#pragma unroll
+                    for (int b = 0; b < KMAX; b += 2) {
+                        const double2 c2 = *reinterpret_cast<const double2*>(cvec + b);
+                        r_a = fma(myR[b], c2.x, r_a);
+                        r_a = fma(myR[b + 1], c2.y, r_a);
+                    }
+                    r_a = s_live ? r_a : 0.0;
+                    rvec[j] = r_a;
+                    wcqp::wave_lds_fence();
+                    // primal step z = tp - sum_a r_a Tc[a]
+#pragma unroll
+                    for (int a = 0; a < KMAX; a += 2) {
+                        const double2 r2 = *reinterpret_cast<const double2*>(rvec + a);
+                        z0 = fma(-r2.x, tc0[a], z0); z1 = fma(-r2.x, tc1[a], z1);
+                        z0 = fma(-r2.y, tc0[a + 1], z0); z1 = fma(-r2.y, tc1[a + 1], z1);
+                    }
+                    zb[j] = z0; zb[col1] = z1;
+                    wcqp::wave_lds_fence();
+                    nzv = sig * zb[p];                       // Schur complement of the bordered system
+                    ratio = (s_live && r_a > 0.0) ? s_mu * wcqp::fast_rcp(r_a) : inf;
+                    t1 = row_min(ratio);
+                }
+                // a full working set (nW == n - meq) leaves no direction; otherwise dependence shows as
+                // a vanishing Schur complement
+                const double inz = wcqp::fast_rcp(nzv);
+                const double t2 = (nW < KMAX && nzv > 1e-10 * ppp) ? s * inz : inf;
+                const double t = fmin(t1, t2);
+                if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; done = true; }
+                else {
+                    nu0 = fma(-t, z0, nu0);
+                    nu1 = fma(-t, z1, nu1);
+                    s_mu = s_live ? s_mu - t * r_a : s_mu;
+                    mu_p += t;
+                    s -= t * nzv;
+                    if (t2 <= t1) {
+                        // full step: p enters the first free slot; Rinv <- bordered inverse
+                        const unsigned fm = (unsigned)((__ballot(j < KMAX && !s_live) >> (16 * grp)) & 0xffffull);
+                        const int n = fm ? __ffs(fm) - 1 : 0;
+                        const double ra_inz = r_a * inz;         // 0 on lanes without a live slot
+                        const bool me = j == n;
+                        if (nW > 0) {
+#pragma unroll
+                            for (int b = 0; b < KMAX; b += 2) {
+                                const double2 r2 = *reinterpret_cast<const double2*>(rvec + b);
+                                const double u0 = me ? -r2.x * inz : fma(ra_inz, r2.x, myR[b]);
+                                const double u1 = me ? -r2.y * inz : fma(ra_inz, r2.y, myR[b + 1]);
+                                if (j < KMAX) { myR[b] = u0; myR[b + 1] = u1; }
+                            }
+                            wcqp::wave_lds_fence();
+                            if (j < KMAX) myR[n] = me ? inz : -ra_inz;
+                        } else if (me) {
+                            myR[n] = inz;
+                        }
+                        if (me) { s_live = true; s_var = p; s_sg = sig; s_mu = mu_p; Wi[n] = p; }
+#pragma unroll
+                        for (int a = 0; a < KMAX; ++a) { tc0[a] = (a == n) ? tp0 : tc0[a]; tc1[a] = (a == n) ? tp1 : tc1[a]; }
+                        if (p == j) { in_w0 = true; sig0 = sig; }
+                        if (p == col1) { in_w1 = true; sig1 = sig; }
+                        ++nW;
+                        pending = false;
+                    } else {
+                        // partial step: the blocking constraint leaves the working set; Rinv <- downdated inverse
+                        const unsigned dm = (unsigned)((__ballot(ratio == t1) >> (16 * grp)) & 0xffffull);
+                        const int jd = dm ? __ffs(dm) - 1 : 0;
+                        const int wdrop = Wi[jd];
+                        const double* dR = Rinv + jd * LDR;
+                        const double djj = dR[jd];
+                        const double f = (s_live && j != jd) ? dR[j < KMAX ? j : 0] * wcqp::fast_rcp(djj) : 0.0;      // Rinv is symmetric
+                        double u[KMAX];
+#pragma unroll
+                        for (int b = 0; b < KMAX; ++b) u[b] = (j == jd) ? 0.0 : fma(-f, dR[b], myR[b]);
+                        wcqp::wave_lds_fence();
+                        if (j < KMAX) {
+#pragma unroll
+                            for (int b = 0; b < KMAX; ++b) myR[b] = u[b];
+                            myR[jd] = 0.0;
+                        }
+                        if (j == jd) { s_live = false; s_mu = 0.0; }
+                        if (wdrop == j) { in_w0 = false; sig0 = 0.0; }
+                        if (wdrop == col1) { in_w1 = false; sig1 = 0.0; }
+                        --nW;
+                        ++it;
+                    }
+                }
+            }
+            wcqp::wave_lds_fence();
+        }
+        WCQP_STAMP(15);
         // certificate: every bound holds and every active bound is tight, else the walk lost accuracy
         {
             const double d0 = !bnd0 ? 0.0 : (in_w0 ? fabs(nu0 - (sig0 > 0.0 ? hi0 : lo0)) : fmax(nu0 - hi0, lo0 - nu0));
             const double d1 = !bnd1 ? 0.0 : (in_w1 ? fabs(nu1 - (sig1 > 0.0 ? hi1 : lo1)) : fmax(nu1 - hi1, lo1 - nu1));
             const double dev = fmax(d0 == d0 ? d0 : inf, d1 == d1 ? d1 : inf);
-            const double worst = row_max(dev);
-            if (st_code == WCQP_STATUS_SOLVED && worst > 1e-9) st_code = WCQP_STATUS_NUMERIC;
+            const unsigned bad = row_max_u32((dev > 1e-9) ? 1u : 0u);
+            if (st_code == WCQP_STATUS_SOLVED && bad != 0u) st_code = WCQP_STATUS_NUMERIC;
             if (st_code == WCQP_STATUS_SOLVED && in_w0) nu0 = sig0 > 0.0 ? hi0 : lo0;
             if (st_code == WCQP_STATUS_SOLVED && in_w1) nu1 = sig1 > 0.0 ? hi1 : lo1;
         }
@@ -678,7 +767,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         wcqp::wave_lds_fence();
         if (j < 12 && live) {
             const double* jrow = (j < 6 ? JL + inst * (6 * kNV) + j * kNV : JR + inst * (6 * kNV) + (j - 6) * kNV);
-            double acc = bvec[j];
+            double acc = b_mine;
             for (int k = 0; k < kNV; ++k) acc = fma(-jrow[k], nub[k], acc);
             ferr_out[inst * 12 + j] = acc;           // b - J nu (osqp.cpp:430-454, qp.cpp:364-401)
         }
