@@ -545,15 +545,30 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     return;
 #endif
     if (ferr_out) {
-        double* nub = S + L::OFF_F;                  // F is dead now
+        // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401): every lane multiplies its
+        // column (reloaded, L2-resident) by its velocity, a [12][34] LDS tile turns the 32 partial
+        // products of a row over to lane r
+        static_assert(12 * 34 <= L::OFF_B, "the tile fits in front of the task rhs");
+        double* pb = S;
+        const int ic = var ? i : kNV - 1;
+        const double v = var ? nu : 0.0;
+        const double* jl = JL + inst * (6 * kNV) + ic;
+        const double* jr = JR + inst * (6 * kNV) + ic;
+        double part[12];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { part[r] = jl[r * kNV] * v; part[6 + r] = jr[r * kNV] * v; }
         wcqp::wave_lds_fence();
-        nub[i] = var ? nu : 0.0;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) pb[r * 34 + i] = part[r];
         wcqp::wave_lds_fence();
         if (i < 12 && live) {
-            const double* jrow = (i < 6 ? JL + inst * (6 * kNV) + i * kNV : JR + inst * (6 * kNV) + (i - 6) * kNV);
             double acc = bvec[i];
-            for (int k = 0; k < kNV; ++k) acc = fma(-jrow[k], nub[k], acc);
-            ferr_out[inst * 12 + i] = acc;           // b - J nu (osqp.cpp:430-454, qp.cpp:364-401)
+#pragma unroll
+            for (int k = 0; k < 32; k += 2) {
+                const double2 p2 = *reinterpret_cast<const double2*>(pb + i * 34 + k);
+                acc -= p2.x; acc -= p2.y;
+            }
+            ferr_out[inst * 12 + i] = acc;
         }
     }
 }

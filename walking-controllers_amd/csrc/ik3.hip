@@ -760,16 +760,32 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     return;
 #endif
     if (ferr_out) {
-        double* nub = S + OFF_P;
+        // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401): every lane multiplies its two
+        // columns (reloaded, L2-resident) by its two velocities, a [12][18] LDS tile turns the 16 partial
+        // sums of a row over to lane r
+        double* pb = S + OFF_P;
+        const int c1 = var1 ? col1 : kNV - 1;
+        const double v1 = var1 ? nu1 : 0.0;
+        const double* jl = JL + inst * (6 * kNV);
+        const double* jr = JR + inst * (6 * kNV);
+        double part[12];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            part[r] = fma(jl[r * kNV + j], nu0, jl[r * kNV + c1] * v1);
+            part[6 + r] = fma(jr[r * kNV + j], nu0, jr[r * kNV + c1] * v1);
+        }
         wcqp::wave_lds_fence();
-        nub[j] = nu0;
-        nub[col1] = var1 ? nu1 : 0.0;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) pb[r * 18 + j] = part[r];
         wcqp::wave_lds_fence();
         if (j < 12 && live) {
-            const double* jrow = (j < 6 ? JL + inst * (6 * kNV) + j * kNV : JR + inst * (6 * kNV) + (j - 6) * kNV);
             double acc = b_mine;
-            for (int k = 0; k < kNV; ++k) acc = fma(-jrow[k], nub[k], acc);
-            ferr_out[inst * 12 + j] = acc;           // b - J nu (osqp.cpp:430-454, qp.cpp:364-401)
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                const double2 p2 = *reinterpret_cast<const double2*>(pb + j * 18 + k);
+                acc -= p2.x; acc -= p2.y;
+            }
+            ferr_out[inst * 12 + j] = acc;
         }
     }
 }
