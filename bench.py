@@ -165,15 +165,17 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    mpc_ev = torch.cuda.Event(enable_timing=True)
+    # HIP events around the IK launch of every `stride`-th timed step (a pair of event records costs about
+    # as much as a launch, so bracketing every step would slow the thing being measured)
+    stride = max(1, int(os.environ.get("WCQP_BENCH_EVENT_STRIDE", str(max(1, min(8, args.steps // 8))))))
+    events = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, stride)}
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        step(events.get(k))
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(dist, torch, dev, elapsed)
-    ik_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))      # IK kernel, HIP events on its stream
+    ik_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))      # IK kernel, HIP events on its stream
     # MPC kernel duration: a short separately timed run (it is not the dominant kernel)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)

@@ -291,3 +291,20 @@ def test_ik_properties_at_full_size(wca):
                         b["q"][perm], b["state"][perm])
     assert np.array_equal(out2["dq"], dq[perm])                          # bitwise, whatever the lane half
     assert np.array_equal(out2["active_upper"], up[perm])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 2, 3, 5, 7, 4095])
+def test_ik_16lane_kernel_on_ragged_batches(wca, batch):
+    """The 16-lane kernel packs 4 instances per wave: batches that leave 1..3 of a wave's rows
+    without an instance must give, row for row, what the 32-lane kernel gives (same optimum,
+    same active sets, same foot errors), and must not touch memory past the batch."""
+    b = wca.synth.synth_ik_batch(batch, seed=77)
+    args = (b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    ref = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, algorithm=3).solve_host(*args)
+    out = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, algorithm=4).solve_host(*args)
+    assert (out["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert np.abs(out["dq"][ok] - ref["dq"][ok]).max(initial=0.0) <= 1e-10
+    assert (out["active_lower"][ok] == ref["active_lower"][ok]).all() and (out["active_upper"][ok] == ref["active_upper"][ok]).all()
+    assert np.abs(out["foot_err"][ok] - ref["foot_err"][ok]).max(initial=0.0) <= 1e-10

@@ -21,10 +21,7 @@ t = dbg.cpu().numpy().reshape(nw, 16)[:, :10].astype(np.float64)
 seg = np.diff(t, axis=1)
 names = ["loads", "rhs+grad", "gauss-jordan", "rows->tables", "Hr build", "sweep", "x_N,x_B", "active set", "outputs"]
 full = dbg.cpu().numpy().reshape(nw, 16).astype(np.float64)
-gj = {"gi: init": float(np.median(full[:, 10] - full[:, 7])), "first bound (straight-line)": float(np.median(full[:, 14] - full[:, 10])), "general loop": float(np.median(full[:, 15] - full[:, 14])), "cert+rest": float(np.median(full[:, 8] - full[:, 15]))} if alg == 4 else {"panel0 (4 steps + trailing)": float(np.median(full[:, 14] - full[:, 2])),
-      "panel1 step0": float(np.median(full[:, 10] - full[:, 14])), "panel1 step1": float(np.median(full[:, 11] - full[:, 10])),
-      "panel1 step2": float(np.median(full[:, 12] - full[:, 11])), "panel1 step3": float(np.median(full[:, 13] - full[:, 12])),
-      "panel1 trailing": float(np.median(full[:, 15] - full[:, 13]))}
+gj = {"gi: init": float(np.median(full[:, 10] - full[:, 7])), "first bound (straight-line)": float(np.median(full[:, 14] - full[:, 10])), "general loop": float(np.median(full[:, 15] - full[:, 14])), "cert+rest": float(np.median(full[:, 8] - full[:, 15]))} if alg == 4 else {}
 print(json.dumps({"gj_detail": gj}))
 print(json.dumps({"B": B, "vmax": vmax, "median_cycles": dict(zip(names, np.median(seg, 0).tolist())),
                   "total_median": float(np.median(t[:, 9] - t[:, 0])), "span_all_waves": float(t[:, 9].max() - t[:, 0].min())}))

@@ -4,9 +4,9 @@
 // chosen after profiling ik.hip (53 % of wave cycles parked on LDS round trips, 6 k
 // instructions and 256 VGPRs per instance pair):
 //
-//   1. Gauss-Jordan on [A | b] with column pivoting.  Lane j holds COLUMN j of A in registers
-//      (lane 29 holds b, so the right-hand side rides along for free).  After meq steps the
-//      basic variables are  x_B = b' - F x_N  and only nN = 29 - meq = 14 variables are free.
+//   1. Gauss-Jordan on [A | b] with column pivoting, rows in panels of 4.  Lane j holds COLUMN j
+//      of A in registers (lane 29 holds b, so the right-hand side rides along for free).  After
+//      meq steps the basic variables are  x_B = b' - F x_N  and only nN = 29 - meq = 14 are free.
 //   2. Reduced Hessian  Hr = Z'HZ = D_N + F'D_B F + (N Z)'W(N Z)  (14 x 14, SPD whenever the
 //      KKT matrix is regular — H itself is only PSD) built row-per-lane over the free lanes,
 //      addressed through a compact index (prefix count of free lanes).
@@ -22,7 +22,7 @@ namespace {
 
 using namespace wcqp_ik;
 
-// Diagnostic builds only (tools/stamps.sh): s_memtime at phase boundaries, written by lane 0 of
+// Diagnostic builds only (tools/build_variant.sh stamps -DWCQP_IK_STAMPS, tools/stamps.py): s_memtime at phase boundaries, written by lane 0 of
 // each wave into the foot-error buffer (never an output in that build).  No stamp exists in the
 // product build.
 #ifdef WCQP_IK_STAMPS
@@ -252,7 +252,6 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                     }
                     a[r] = t;
                 }
-                if (r0 == 4) WCQP_STAMP(10 + s);        // diagnostic build: second panel, step by step
             }
             if (myrow >= r0) {
                 double* c = cb + (myrow - r0) * 16;
@@ -279,8 +278,6 @@ void ik2_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 if (q == (r0 < 8 ? 8 : 4)) wcqp::pin_result(a[q]);
             }
             wcqp::wave_lds_fence();
-            if (r0 == 0) WCQP_STAMP(14);
-            if (r0 == 4) WCQP_STAMP(15);
         }
     }
     const bool basic = myrow >= 0;

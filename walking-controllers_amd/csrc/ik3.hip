@@ -228,11 +228,9 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const int p = 31 - (int)(key & 31u);    // pivot column
                 myrow0 = (p == j) ? r : myrow0;
                 myrow1 = (p == col1) ? r : myrow1;
-#ifndef WCQP_IK3_NOPIN
                 wcqp::pin_value(kmin);
                 wcqp::pin_value(myrow0);
                 wcqp::pin_value(myrow1);
-#endif
                 const int src = (rowbase + (p & 15)) << 2;
                 double c[4];
 #pragma unroll
