@@ -290,7 +290,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
             "batch_per_gpu": B, "global_batch": B * world, "horizon": 50, "dof": 23, "ticks": args.steps,
             "parallelism": "batch sharded over %d GPU(s), no data-path collective" % world,
         },
-        "roofline": {"bound": "hbm", "kernel": "whole tick (4 launches: mpc_condensed, tick_glue, ik3|ik2, tick_post)", "achieved": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "whole tick (2 launches: mpc_condensed, ik3_kernel<TICK> with glue and post fused)", "achieved": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "avg_launch_ms": dev_ms, "algorithmic_bytes_per_launch": bytes_per_tick * B},
         "solved": {"ticks_executed": out_state["tick"], "mpc_fail": int(out_state["mpc_fail"].sum()),

@@ -27,7 +27,10 @@ def test_contact_schedule_and_reference_are_consistent(wca):
 
 
 @pytest.mark.gpu
-def test_tick_pipeline_matches_cpu_restatement(wca, qs):
+@pytest.mark.parametrize("ik_algorithm", [0, 3], ids=["fused_2_launches", "4_launches"])
+def test_tick_pipeline_matches_cpu_restatement(wca, qs, ik_algorithm):
+    """Default IK algorithm: glue and post steps run inside the 16-lane IK kernel (2 launches per tick);
+    an explicit 32-lane algorithm keeps the stand-alone glue / post kernels (4 launches per tick)."""
     from oracle import tick_spec as ts
     B, T = 24, 150            # > one contact change per instance (double support lasts 110 ticks)
     p = ts.TickParams()
@@ -36,7 +39,7 @@ def test_tick_pipeline_matches_cpu_restatement(wca, qs):
     ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax * np.ones(23)))
     assert ref["mpc_fail"].sum() == 0 and ref["ik_fail"].sum() == 0
     for use_graph in (False, True):
-        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax), log_ticks=T)
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm), log_ticks=T)
         pipe.upload(d)
         pipe.run(T, use_graph=use_graph)
         out = pipe.download()

@@ -431,6 +431,7 @@ int ensure_device(wcqp_ik_s* h) {
 
 namespace wcqp {
 int ik_prepare(wcqp_ik_t h) { return h ? ensure_device(h) : WCQP_E_INVALID; }
+const void* ik_device_params(wcqp_ik_t h) { return h ? h->d_prm : nullptr; }
 }  // namespace wcqp
 
 extern "C" {

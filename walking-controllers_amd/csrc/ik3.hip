@@ -14,6 +14,7 @@
 #include <cmath>
 #include <limits>
 #include "ik_common.h"
+#include "tick_device.h"
 
 namespace {
 
@@ -96,6 +97,10 @@ __device__ __forceinline__ double row_max(double v) {
 }
 __device__ __forceinline__ unsigned mag_key(double v) { return __float_as_uint((float)fabs(v)) & ~31u; }
 
+// TICK: the receding-horizon pipeline's glue (ZMP-CoM law, plant; tick_device.h) runs in the prologue
+// and its post step (joint integration, next contact pair, tick counter) in the epilogue, so that a
+// tick is two launches (MPC, this) instead of four.
+template <bool TICK>
 __global__ __launch_bounds__(64, 2)
 void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -103,7 +108,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ qpos, const double* __restrict__ state,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
-                double* __restrict__ ferr_out, int* __restrict__ iters_out)
+                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
 
@@ -122,6 +127,9 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const bool rhs1 = j == kNV - 16;                // column 29 = b
     const int col1 = j + 16;
 
+    int tick_now = 0;
+    if constexpr (TICK) tick_now = *td.tick_latched;
+
     WCQP_STAMP(0);
     // ---------------- phase 0: loads ------------------------------------------------------------
     const double Di0 = prm->lam[j], Di1 = prm->lam[col1];
@@ -137,6 +145,19 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
         const double q0 = qpos[inst * kDof + j];
         const double q1 = qpos[inst * kDof + (16 + j < kDof ? 16 + j : 0)];
+        // tick pipeline: this tick's desired CoM (lanes 0, 1: one axis each) and foot twists (lanes 0..5)
+        // replace what the stored state block holds; issued ahead of the Jacobian loads for the same reason
+        double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0;
+        if constexpr (TICK) {
+            if (live) {
+                const int i_ = (int)inst;
+                const int mst = td.mpc_status[i_];
+                const bool mpc_ok = mst == WCQP_STATUS_SOLVED || mst == WCQP_STATUS_OUTSIDE_HULL;
+                if (j < 2) wcqp_tick::tick_glue_axis(td, i_, tick_now, j, mpc_ok, g_com, g_pstar, g_vel);
+                if (j < 6) wcqp_tick::tick_glue_twist(td, i_, td.sel[i_], j, g_twl, g_twr);
+                if (j == 0 && !mpc_ok) td.mpc_fail[i_] += 1;
+            }
+        }
         const int c1 = var1 ? col1 : kNV - 1;       // lanes 13..15 reload column 28 (never used)
         const double* jl = JL + inst * (6 * kNV);
         const double* jr = JR + inst * (6 * kNV);
@@ -155,6 +176,12 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         if (80 + j < kStateLen) st[80 + j] = sreg[5];
         st[kStateLen + j] = q0;
         if (16 + j < kDof) st[kStateLen + 16 + j] = q1;
+        if constexpr (TICK) {
+            wcqp::wave_lds_fence();
+            if (j < 2) { st[66 + j] = g_com; st[69 + j] = g_pstar; st[72 + j] = g_vel; }
+            if (j < 6) { st[75 + j] = g_twl; st[81 + j] = g_twr; }
+            if (j == 0) wcqp_tick::tick_glue_height(td, st);
+        }
     }
     wcqp::wave_lds_fence();
 
@@ -757,6 +784,18 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     WCQP_STAMP(9);
     return;
 #endif
+    if constexpr (TICK) {
+        const bool ik_ok = st_code == WCQP_STATUS_SOLVED;
+        if (live) {
+            const int i_ = (int)inst;
+            if (j >= 6) wcqp_tick::tick_post_joint(td, i_, tick_now, j - 6, ik_ok, nu0);
+            if (var1) wcqp_tick::tick_post_joint(td, i_, tick_now, j + 10, ik_ok, nu1);
+            if (j == 0) wcqp_tick::tick_post_instance(td, i_, tick_now, ik_ok);
+        }
+        // advanceReferenceSignals (WalkingModule.cpp:816): every kernel after the MPC reads the tick index
+        // from the copy the MPC kernel made, so `tick` itself may advance as soon as this kernel runs
+        if (blockIdx.x == 0 && lane == 0) *td.tick = tick_now + 1;
+    }
     if (ferr_out) {
         // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401): every lane multiplies its two
         // columns (reloaded, L2-resident) by its two velocities, a [12][18] LDS tile turns the 16 partial
@@ -797,8 +836,19 @@ int ik3_launch(const IkDeviceParams* d_prm, int batch,
                const double* q, const double* state, double* dq, int* status,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
     const unsigned grid = (unsigned)((batch + 3) / 4);
-    hipLaunchKernelGGL(ik3_kernel, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
-                       dq, status, alo, aup, ferr, iters);
+    hipLaunchKernelGGL(ik3_kernel<false>, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+                       dq, status, alo, aup, ferr, iters, wcqp_tick::TickDev{});
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+int ik3_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
+                    const double* JL, const double* JR, const double* JN, const double* JC,
+                    unsigned* alo, unsigned* aup, hipStream_t stream) {
+    if (!d_prm) return WCQP_E_INVALID;
+    const unsigned grid = (unsigned)((td.batch + 3) / 4);
+    hipLaunchKernelGGL(ik3_kernel<true>, dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
+                       JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }

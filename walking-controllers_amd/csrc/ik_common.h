@@ -284,3 +284,11 @@ int ik3_launch(const IkDeviceParams* d_prm, int batch,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream);
 
 }  // namespace wcqp_ik
+
+namespace wcqp_tick { struct TickDev; }
+namespace wcqp_ik {
+// the 16-lane kernel with the tick pipeline's glue and post steps fused in (tick.hip)
+int ik3_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
+                    const double* JL, const double* JR, const double* JN, const double* JC,
+                    unsigned* alo, unsigned* aup, hipStream_t stream);
+}  // namespace wcqp_ik

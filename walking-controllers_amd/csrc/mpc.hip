@@ -55,7 +55,7 @@ struct MpcDeviceConsts {
 __global__ __launch_bounds__(kBlock)
 void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
                           const double* __restrict__ x0, const double* __restrict__ ref, int ref_len,
-                          int ref_stride, const int* __restrict__ ref_start,
+                          int ref_stride, const int* __restrict__ ref_start, int* __restrict__ ref_start_copy,
                           const double* __restrict__ u_prev,
                           const double* __restrict__ hull_A, const double* __restrict__ hull_b,
                           const int* __restrict__ hull_nc, int hull_sets, const int* __restrict__ hull_sel,
@@ -74,7 +74,11 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
     // ---- u0_unc = sum_i Gr_i r_i + Gx x0 + Gu u_prev ---------------------------------
     // the reference window of an instance starts `*ref_start` stages into its trajectory (the
     // deque of the reference advanced by that many ticks); instances are `ref_stride` stages apart
-    const double2* rp = reinterpret_cast<const double2*>(ref) + inst * ref_stride + (ref_start ? *ref_start : 0);
+    const int start = ref_start ? *ref_start : 0;
+    // tick pipeline: the next kernel of the tick reads the tick index from this copy, so that it may
+    // advance `*ref_start` itself while some of its workgroups have not started yet
+    if (ref_start_copy && blockIdx.x == 0 && lane == 0) *ref_start_copy = start;
+    const double2* rp = reinterpret_cast<const double2*>(ref) + inst * ref_stride + start;
     const double2* gp = reinterpret_cast<const double2*>(c.Gr);
     double ux = 0.0, uy = 0.0;
     // 64 stages per pass: the four reference loads of a lane (stages t, t+16, t+32, t+48) are
@@ -329,7 +333,7 @@ int ensure_device(wcqp_mpc_s* h) {
 namespace wcqp {
 
 int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, int ref_len, int ref_stride,
-                const int* ref_start_dev, const double* u_prev,
+                const int* ref_start_dev, int* ref_start_copy_dev, const double* u_prev,
                 const double* hull_A, const double* hull_b, const int* hull_nc, int hull_sets, const int* hull_sel,
                 double* u0, int* status, unsigned* active, double* margin, hipStream_t stream) {
     if (!h || batch < 0 || ref_len < 1 || ref_stride < ref_len || hull_sets < 1) return WCQP_E_INVALID;
@@ -347,7 +351,7 @@ int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, in
     c.N = h->N;
     const unsigned grid = (unsigned)((batch + kInstPerWave - 1) / kInstPerWave);
     hipLaunchKernelGGL(mpc_condensed_kernel, dim3(grid), dim3(kBlock), 0, stream,
-                       c, batch, x0, ref, ref_len, ref_stride, ref_start_dev, u_prev, hull_A, hull_b, hull_nc, hull_sets, hull_sel,
+                       c, batch, x0, ref, ref_len, ref_stride, ref_start_dev, ref_start_copy_dev, u_prev, hull_A, hull_b, hull_nc, hull_sets, hull_sel,
                        u0, status, active, margin);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
@@ -409,7 +413,7 @@ int wcqp_mpc_solve_device(wcqp_mpc_t h, int32_t batch,
                           const double* x0, const double* ref, int32_t ref_len, const double* u_prev,
                           const double* hull_A, const double* hull_b, const int32_t* hull_nc,
                           double* u0, int32_t* status, uint32_t* active, double* margin, void* stream) {
-    return wcqp::mpc_enqueue(h, batch, x0, ref, ref_len, ref_len, nullptr, u_prev, hull_A, hull_b, hull_nc, 1, nullptr,
+    return wcqp::mpc_enqueue(h, batch, x0, ref, ref_len, ref_len, nullptr, nullptr, u_prev, hull_A, hull_b, hull_nc, 1, nullptr,
                              u0, status, active, margin, (hipStream_t)stream);
 }
 

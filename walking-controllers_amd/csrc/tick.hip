@@ -14,91 +14,25 @@
 #include <vector>
 #include "wcqp_internal.h"
 
+#include "tick_device.h"
+#include "ik_common.h"
+
 namespace {
 
-constexpr int kDof = 23;
-constexpr int kStateLen = WCQP_IK_STATE_LEN;
-
-struct TickDev {
-    // per-instance constants
-    const double* ref_traj; const double* hull_tab_A; const double* hull_tab_b; const int* hull_tab_nc;
-    const int* phase0; const double* swing_twist;
-    // per-instance state
-    double *dcm, *com, *zmp_meas, *u_prev, *u0, *c_ref, *v_ref, *p_star, *v_star_prev, *v_ref_prev;
-    double *q_des, *dq_prev, *dq, *state;
-    int *sel, *mpc_status, *ik_status;     // sel: contact pair of the CURRENT tick (0 left, 1 right, 2 both)
-    long long *mpc_fail, *ik_fail;
-    int* tick;          // ticks completed; read by the MPC window and the glue
-    int* tick_latched;  // copy made by the glue for the post kernel, which then advances `tick`
-    double *u0_log, *dq_log;
-    // scalars
-    int batch, first, traj_len, log_ticks, step_ticks, ds_ticks;
-    double omega, a, b, dT, k_com, k_zmp, noise, com_height;
-    unsigned long long seed;
-};
-
-__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27; x *= 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return x;
-}
-// uniform in [-1, 1): identical integer arithmetic to oracle/tick_spec.py::disturbance
-__device__ __forceinline__ double disturbance(unsigned long long seed, unsigned long long inst, int tick, int axis) {
-    const unsigned long long base = mix64(inst * 0x9E3779B97F4A7C15ull + seed);
-    const unsigned long long h = mix64(base + ((unsigned long long)(2 * tick + axis) + 1ull) * 0x94D049BB133111EBull);
-    return (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
-}
-
-__device__ __forceinline__ int contact_code(int t, int phase0, int step_ticks, int ds_ticks) {
-    const int cyc = (t + phase0) % (2 * step_ticks);
-    const int s = cyc % step_ticks, side = cyc / step_ticks;
-    return s < ds_ticks ? 2 : side;                 // 0 = left only, 1 = right only, 2 = both
-}
+using namespace wcqp_tick;
 
 __global__ void tick_glue_kernel(TickDev d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.batch) return;
-    const int t = *d.tick;
-    if (i == 0) *d.tick_latched = t;
+    const int t = *d.tick_latched;       // copy made by the MPC kernel of this tick
     const int code = d.sel[i];
     const int st = d.mpc_status[i];
-    // StableDCMModel::integrateModel (StableDCMModel.cpp:63-90), Tustin integrator; it precedes the
-    // MPC in the reference (WalkingModule.cpp:578-597) but only the ZMP-CoM law below consumes it
-    for (int ax = 0; ax < 2; ++ax) {
-        const double r = d.ref_traj[((size_t)i * d.traj_len + t) * 2 + ax];
-        const double v = -d.omega * (d.c_ref[2 * i + ax] - r);
-        d.c_ref[2 * i + ax] += 0.5 * d.dT * (v + d.v_ref_prev[2 * i + ax]);
-        d.v_ref_prev[2 * i + ax] = v;
-        d.v_ref[2 * i + ax] = v;
-    }
     const bool ok = st == WCQP_STATUS_SOLVED || st == WCQP_STATUS_OUTSIDE_HULL;
     if (!ok) d.mpc_fail[i] += 1;
     double* s = d.state + (size_t)i * kStateLen;
-    for (int ax = 0; ax < 2; ++ax) {
-        const double u = ok ? d.u0[2 * i + ax] : d.u_prev[2 * i + ax];     // hold the last command on failure
-        // WalkingZMPController::evaluateControl (WalkingZMPController.cpp:146-173)
-        const double v = d.k_com * (d.c_ref[2 * i + ax] - d.com[2 * i + ax]) - d.k_zmp * (u - d.zmp_meas[2 * i + ax]) + d.v_ref[2 * i + ax];
-        d.p_star[2 * i + ax] += 0.5 * d.dT * (v + d.v_star_prev[2 * i + ax]);
-        d.v_star_prev[2 * i + ax] = v;
-        // desired CoM for the IK (WalkingModule.cpp:686-695)
-        s[66 + ax] = d.com[2 * i + ax];
-        s[69 + ax] = d.p_star[2 * i + ax];
-        s[72 + ax] = v;
-        // synthetic plant: LIPM with a bounded disturbance
-        const double xi = d.dcm[2 * i + ax];
-        d.com[2 * i + ax] += d.dT * (-d.omega * (d.com[2 * i + ax] - xi));
-        d.dcm[2 * i + ax] = d.a * xi + d.b * u + d.noise * disturbance(d.seed, (unsigned long long)(d.first + i), t, ax);
-        d.zmp_meas[2 * i + ax] = u;
-        d.u_prev[2 * i + ax] = u;
-        if (t < d.log_ticks) d.u0_log[((size_t)t * d.batch + i) * 2 + ax] = u;
-    }
-    s[68] = d.com_height; s[71] = d.com_height; s[74] = 0.0;
-    for (int k = 0; k < 6; ++k) {
-        const double tw = d.swing_twist[(size_t)i * 6 + k];
-        s[75 + k] = (code == 0 || code == 2) ? 0.0 : tw;      // a foot in contact keeps a zero twist
-        s[81 + k] = (code == 1 || code == 2) ? 0.0 : tw;
-    }
+    for (int ax = 0; ax < 2; ++ax) tick_glue_axis(d, i, t, ax, ok, s[66 + ax], s[69 + ax], s[72 + ax]);
+    tick_glue_height(d, s);
+    for (int k = 0; k < 6; ++k) tick_glue_twist(d, i, code, k, s[75 + k], s[81 + k]);
 }
 
 __global__ void tick_post_kernel(TickDev d) {
@@ -107,17 +41,8 @@ __global__ void tick_post_kernel(TickDev d) {
     const int i = g / kDof;
     const int t = *d.tick_latched;
     const bool ok = d.ik_status[i] == WCQP_STATUS_SOLVED;
-    const double v = ok ? d.dq[g] : 0.0;
-    if (!ok && g % kDof == 0) d.ik_fail[i] += 1;
-    d.q_des[g] += 0.5 * d.dT * (v + d.dq_prev[g]);             // WalkingModule.cpp:741-744
-    d.dq_prev[g] = v;
-    if (t < d.log_ticks) d.dq_log[(size_t)t * d.batch * kDof + g] = v;
-    if (g % kDof == 0) {
-        // contact pair of the NEXT tick: WalkingController::setConvexHullConstraint switches rows only
-        // when the pair changes (…PredictiveController.cpp:369-374) — here the MPC kernel simply
-        // reads the row set this index selects
-        d.sel[i] = contact_code(t + 1, d.phase0[i], d.step_ticks, d.ds_ticks);
-    }
+    tick_post_joint(d, i, t, g % kDof, ok, d.dq[g]);
+    if (g % kDof == 0) tick_post_instance(d, i, t, ok);
     if (g == 0) *d.tick = t + 1;      // advanceReferenceSignals (WalkingModule.cpp:816); nobody reads `tick` any more this tick
 }
 
@@ -136,6 +61,7 @@ struct wcqp_tick_s {
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;
     bool uploaded = false;
+    bool fused = false;      // glue + post inside the 16-lane IK kernel: 2 launches per tick instead of 4
 };
 
 namespace {
@@ -154,10 +80,13 @@ int enqueue_tick(wcqp_tick_s* h, hipStream_t s) {
     const TickDev& d = h->d;
     const int B = d.batch;
     const int N = wcqp::mpc_horizon(h->mpc);
-    int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick, d.u_prev,
+    int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick, d.tick_latched, d.u_prev,
                                d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, 3, d.sel,
                                d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
     if (rc != WCQP_OK) return rc;
+    if (h->fused)
+        return wcqp_ik::ik3_launch_tick(wcqp::ik_device_params(h->ik), d, h->J_left, h->J_right, h->J_neck, h->J_com,
+                                        h->ik_lo, h->ik_up, s);
     hipLaunchKernelGGL(tick_glue_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d);
     rc = wcqp_ik_solve_device(h->ik, B, h->J_left, h->J_right, h->J_neck, h->J_com, d.q_des, d.state,
                               d.dq, d.ik_status, h->ik_lo, h->ik_up, nullptr, nullptr, s);
@@ -183,6 +112,10 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     wcqp_tick_s* h = new (std::nothrow) wcqp_tick_s();
     if (!h) return WCQP_E_NOMEM;
     h->p = *params;
+    // the fused form exists for the 16-lane kernel only (CoM as constraint); an explicit 32-lane / sweep
+    // algorithm keeps the four-launch form, which is also what the fused one is tested against
+    h->fused = params->ik.use_com_as_constraint &&
+               (params->ik.algorithm == WCQP_IK_ALG_DEFAULT || params->ik.algorithm == WCQP_IK_ALG_NULLSPACE_16L);
     int rc = wcqp_mpc_create(&params->mpc, &h->mpc);
     if (rc == WCQP_OK) rc = wcqp_ik_create(&params->ik, &h->ik);
     if (rc == WCQP_OK) rc = wcqp::mpc_prepare(h->mpc);
@@ -270,7 +203,7 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         return WCQP_OK;
     }
     if (!h->graph_exec) {
-        // one tick = four launches, captured once; the tick index lives in HBM so the graph is tick-invariant
+        // one tick = two (fused) or four launches, captured once; the tick index lives in HBM so the graph is tick-invariant
         hipStream_t cs = nullptr;
         WCQP_HIP_TRY(hipStreamCreate(&cs));
         // a first plain tick would advance the state, so make sure lazy device state of the solver

@@ -32,12 +32,13 @@ struct DeviceScratch {
 
 // internal launch of the MPC kernel with a strided / offset reference window (tick pipeline)
 int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, int ref_len, int ref_stride,
-                const int* ref_start_dev, const double* u_prev,
+                const int* ref_start_dev, int* ref_start_copy_dev, const double* u_prev,
                 const double* hull_A, const double* hull_b, const int* hull_nc, int hull_sets, const int* hull_sel,
                 double* u0, int* status, unsigned* active, double* margin, hipStream_t stream);
 int mpc_horizon(wcqp_mpc_t h);
 int mpc_prepare(wcqp_mpc_t h);     // uploads the handle's device constants now (graph capture forbids it later)
 int ik_prepare(wcqp_ik_t h);
+const void* ik_device_params(wcqp_ik_t h);     // IkDeviceParams* in HBM (after ik_prepare)
 void mpc_dynamics(wcqp_mpc_t h, double* a, double* b);
 
 // ---- wave-level helpers used by the kernels (gfx950, wave64) -------------------------
