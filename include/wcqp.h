@@ -283,7 +283,7 @@ typedef struct wcqp_tick_s* wcqp_tick_t;
 int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out);
 int wcqp_tick_destroy(wcqp_tick_t h);
 int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in);                 /* also rewinds to tick 0 */
-int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream); /* enqueue only  */
+int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream); /* enqueue only; use_graph: hipGraph replays of 8 ticks each, remainder as plain launches */
 int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out);             /* synchronises     */
 
 #ifdef __cplusplus

@@ -202,14 +202,16 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         for (int k = 0; k < n_ticks; ++k) { const int rc = enqueue_tick(h, s); if (rc != WCQP_OK) return rc; }
         return WCQP_OK;
     }
-    if (!h->graph_exec) {
-        // one tick = two (fused) or four launches, captured once; the tick index lives in HBM so the graph is tick-invariant
+    // kGraphTicks ticks per graph (the tick index lives in HBM, so the graph is tick-invariant): one
+    // hipGraphLaunch costs about as much as four plain launches, a tick is only two
+    constexpr int kGraphTicks = 8;
+    if (!h->graph_exec && n_ticks >= kGraphTicks) {
         hipStream_t cs = nullptr;
         WCQP_HIP_TRY(hipStreamCreate(&cs));
-        // a first plain tick would advance the state, so make sure lazy device state of the solver
-        // handles exists before capture (capture forbids allocations)
+        // (lazy device state of the solver handles exists since create: capture forbids allocations)
         WCQP_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_tick(h, cs);
+        int rc = WCQP_OK;
+        for (int k = 0; k < kGraphTicks && rc == WCQP_OK; ++k) rc = enqueue_tick(h, cs);
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(cs, &g);
         (void)hipStreamDestroy(cs);
@@ -218,7 +220,9 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         h->graph = g;
         WCQP_HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
     }
-    for (int k = 0; k < n_ticks; ++k) WCQP_HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+    int left = n_ticks;
+    for (; h->graph_exec && left >= kGraphTicks; left -= kGraphTicks) WCQP_HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+    for (; left > 0; --left) { const int rc = enqueue_tick(h, s); if (rc != WCQP_OK) return rc; }
     return WCQP_OK;
 }
 
