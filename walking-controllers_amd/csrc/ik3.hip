@@ -258,8 +258,8 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 wcqp::pin_value(kmin);
                 wcqp::pin_value(myrow0);
                 wcqp::pin_value(myrow1);
-                const int src = (rowbase + (p & 15)) << 2;
                 double c[4];
+                const int src = (rowbase + (p & 15)) << 2;
 #pragma unroll
                 for (int u = 0; u < pw; ++u) c[u] = lane_gather(m[u], src);
                 const double t0 = a0[r] * c[s], t1 = a1[r] * c[s];
