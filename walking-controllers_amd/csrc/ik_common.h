@@ -162,6 +162,41 @@ __device__ __forceinline__ void gi_active_set(const GiScratch& w, int i, int hal
     }
     wcqp::wave_lds_fence();
     bool running = st_code == WCQP_STATUS_SOLVED;
+    // First entering bound, empty working set, straight-line: most instances that violate a bound at
+    // all violate exactly one, and the general loop below (nested, group-divergent exits) costs several
+    // times what this does.  With W empty the step is the full step along tau_p: r = 0, z = tau_p,
+    // Schur complement = P[p][p]; the bound takes slot 0.
+    if (running) {
+        const double v_hi = nu - hi, v_lo = lo - nu;
+        const double viol = (var && i >= 6) ? fmax(v_hi, v_lo) : -inf;
+        const double s0 = group_max(viol);
+        if (s0 > tol) {
+            ++it;
+            const int p = group_first(viol == s0, half);
+            w.zbuf[i] = v_hi >= v_lo ? 1.0 : -1.0;
+            wcqp::wave_lds_fence();
+            const double sig = w.zbuf[p];
+            wcqp::wave_lds_fence();
+            const double tp = column_of_P(p, sig);
+            w.tpb[i] = tp;
+            wcqp::wave_lds_fence();
+            const double ppp = sig * w.tpb[p];               // P[p][p] > 0
+            if (ppp > 0.0) {
+                const double inz = 1.0 / ppp;
+                const double t = s0 * inz;
+                nu = fma(-t, tp, nu);
+                if (i == 0) { w.Rinv[0] = inz; s_live = true; s_var = p; s_sg = sig; s_mu = t; w.Wi[0] = p; }
+                tc[0] = tp;
+                if (i == p) { in_w = true; my_sig = sig; }
+                nW = 1; hiW = 1;
+            } else {
+                st_code = WCQP_STATUS_INFEASIBLE; running = false;
+            }
+            wcqp::wave_lds_fence();
+        } else {
+            running = false;
+        }
+    }
     while (running) {
         // most violated bound outside the working set
         const double v_hi = nu - hi, v_lo = lo - nu;
