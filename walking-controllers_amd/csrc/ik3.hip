@@ -133,6 +133,12 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     WCQP_STAMP(0);
     // ---------------- phase 0: loads ------------------------------------------------------------
     const double Di0 = prm->lam[j], Di1 = prm->lam[col1];
+    // batch constants of the rhs / gradient phase: scalar loads issued here, ahead of the global loads,
+    // so that their latency is not paid where they are used
+    const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
+    const double k_pos_foot = prm->k_pos_foot, k_att_foot = prm->k_att_foot, k_pos_com = prm->k_pos_com;
+    const double kap = prm->kappa * (-prm->k_neck);
+    const double kq0 = prm->kq[j], kq1 = prm->kq[col1], qreg0 = prm->qreg[j], qreg1 = prm->qreg[col1];
     double a0[MEQ], a1[MEQ];    // columns j and j + 16 of A = [J_left; J_right; J_com]; lane 13 slot 1: b
     double cn0[NCOST], cn1[NCOST];
     {
@@ -187,7 +193,6 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 
     WCQP_STAMP(1);
     // ---------------- phase 1: task rhs b (lane r < MEQ) and gradient g ---------------------------
-    const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
     double b_mine = 0.0;
     if (j < MEQ) {
         if (j < 12) {
@@ -197,18 +202,17 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             const double* pd = st + (foot ? 36 : 24);
             const double* Rd = st + (foot ? 39 : 27);
             const double* tw = st + (foot ? 81 : 75);
-            const double corr = k < 3 ? prm->k_pos_foot * (p[k] - pd[k]) : prm->k_att_foot * rot_err(R, Rd, k - 3);
+            const double corr = k < 3 ? k_pos_foot * (p[k] - pd[k]) : k_att_foot * rot_err(R, Rd, k - 3);
             const bool skip = osqp_form && tw[0] == tw[1] && tw[0] == 0.0;        // osqp.cpp:286-306
             b_mine = skip ? tw[k] : tw[k] - corr;
         } else {
             const int k = j - 12;
-            b_mine = st[72 + k] - prm->k_pos_com * (st[66 + k] - st[69 + k]);
+            b_mine = st[72 + k] - k_pos_com * (st[66 + k] - st[69 + k]);
         }
         bvec[j] = b_mine;
     }
     double g0, g1;              // gradient entries (osqp.cpp:181-196, qp.cpp:161-178)
     {
-        const double kap = prm->kappa * (-prm->k_neck);
         const double e0 = kap * rot_err(st + 48, st + 57, 0);
         const double e1 = kap * rot_err(st + 48, st + 57, 1);
         const double e2 = kap * rot_err(st + 48, st + 57, 2);
@@ -216,9 +220,9 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         const double y1 = prm->Wn[3] * e0 + prm->Wn[4] * e1 + prm->Wn[5] * e2;
         const double y2 = prm->Wn[6] * e0 + prm->Wn[7] * e1 + prm->Wn[8] * e2;
         g0 = -(cn0[0] * y0 + cn0[1] * y1 + cn0[2] * y2);
-        if (j >= 6) g0 -= prm->kq[j] * (prm->qreg[j] - st[kStateLen + j - 6]);
+        if (j >= 6) g0 -= kq0 * (qreg0 - st[kStateLen + j - 6]);
         g1 = -(cn1[0] * y0 + cn1[1] * y1 + cn1[2] * y2);
-        g1 -= prm->kq[col1] * (prm->qreg[col1] - st[kStateLen + (var1 ? j + 10 : 0)]);
+        g1 -= kq1 * (qreg1 - st[kStateLen + (var1 ? j + 10 : 0)]);
         g1 = var1 ? g1 : 0.0;
     }
     wcqp::wave_lds_fence();
@@ -442,7 +446,9 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     wcqp::wave_lds_fence();
 
     WCQP_STAMP(5);
-    // bounds: fetched here so that the (L2) latency hides under the sweep
+    // bounds and active-set settings: fetched here so that the (L2 / scalar cache) latency hides under the sweep
+    const double tol = prm->tol;
+    const int max_iter = prm->max_iter;
     double lo0 = prm->vlo[j], hi0 = prm->vhi[j], lo1 = prm->vlo[col1], hi1 = prm->vhi[col1];
     // ---------------- phase 4: Hr^-1 (sweep over the NN pivots), x_N, x_B -------------------------
     {
@@ -514,7 +520,6 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     int it = 0;
     bool in_w0 = false, in_w1 = false;
     double sig0 = 0.0, sig1 = 0.0;
-    const double tol = prm->tol;
     const bool bnd0 = j >= 6;                             // the base (columns 0..5) is unbounded
     const bool bnd1 = var1;
     lo0 = bnd0 ? lo0 : -inf; hi0 = bnd0 ? hi0 : inf;
@@ -545,7 +550,6 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         double tc0[KMAX], tc1[KMAX];
         double* myR = Rinv + (j < KMAX ? j : 0) * LDR;
         int nW = 0;
-        const int max_iter = prm->max_iter;
         WCQP_STAMP(10);
         // pending entering bound: variable p, sign, remaining violation s, column tau_p, P[p][p], multiplier
         bool pending = false;
