@@ -308,3 +308,23 @@ def test_ik_16lane_kernel_on_ragged_batches(wca, batch):
     assert np.abs(out["dq"][ok] - ref["dq"][ok]).max(initial=0.0) <= 1e-10
     assert (out["active_lower"][ok] == ref["active_lower"][ok]).all() and (out["active_upper"][ok] == ref["active_upper"][ok]).all()
     assert np.abs(out["foot_err"][ok] - ref["foot_err"][ok]).max(initial=0.0) <= 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vmax", [0.2, 0.12])
+def test_ik_kernels_agree_under_tight_bounds(wca, vmax):
+    """Many active bounds (6..10 per instance, working-set drops, infeasible instances): the three
+    kernels walk the same dual active set, so status, active sets and solutions must coincide
+    (`tools/stress_ik.py` runs the same comparison on 200 k instances)."""
+    B = 4000
+    b = wca.synth.synth_ik_batch(B, seed=303)
+    args = (b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    outs = {a: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=a).solve_host(*args) for a in (4, 3, 1)}
+    ref = outs[3]
+    assert 0.3 * B < (ref["status"] == 0).sum() < B          # a real mix of solved and infeasible instances
+    for a in (4, 1):
+        o = outs[a]
+        assert (o["status"] == ref["status"]).all()
+        ok = ref["status"] == 0
+        assert (o["active_lower"][ok] == ref["active_lower"][ok]).all() and (o["active_upper"][ok] == ref["active_upper"][ok]).all()
+        assert np.abs(o["dq"][ok] - ref["dq"][ok]).max() <= 1e-9
