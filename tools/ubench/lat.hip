@@ -75,6 +75,10 @@ __global__ void k(long long* out, double* sink, const double* in) {
 #pragma unroll
       for (int n = 0; n < 64; ++n) { acc = fma(y, y, acc); x = fma(y, x, x); }   // 2 independent chains
       T1(14); }
+    { T0;
+#pragma unroll
+      for (int n = 0; n < 32; ++n) { x = row_bcast<7>(x) + 1e-9; }
+      T1(15); }                                                        // 32 dependent row_newbcast pairs (+add)
     sink[lane] = x + acc;
 }
 int main() {
@@ -84,8 +88,8 @@ int main() {
     for (int rep = 0; rep < 3; ++rep) k<<<1, 64>>>(d, s, in);
     long long r[16]; hipMemcpy(r, d, sizeof r, hipMemcpyDeviceToHost);
     const char* nm[] = {"empty", "fma_f64 x64", "fma_f32 x64", "fast_rcp x16", "dpp max x64", "permlane16 max x32", "argmax x16", "readlane->fma x32",
-                        "bpermute pair x32", "lds write->read x32", "swizzle pair x32", "group_max f64 x32", "divergent if/else fma x32", "16 b128 reads + 32 fma", "2 chains fma x64"};
-    const int cnt[] = {1, 64, 64, 16, 64, 32, 16, 32, 32, 32, 32, 32, 32, 1, 64};
-    for (int n = 0; n < 15; ++n) std::printf("%-28s %6lld cycles  (%.1f per op)\n", nm[n], r[n], (double)(r[n] - r[0]) / cnt[n]);
+                        "bpermute pair x32", "lds write->read x32", "swizzle pair x32", "group_max f64 x32", "divergent if/else fma x32", "16 b128 reads + 32 fma", "2 chains fma x64", "row_newbcast pair x32"};
+    const int cnt[] = {1, 64, 64, 16, 64, 32, 16, 32, 32, 32, 32, 32, 32, 1, 64, 32};
+    for (int n = 0; n < 16; ++n) std::printf("%-28s %6lld cycles  (%.1f per op)\n", nm[n], r[n], (double)(r[n] - r[0]) / cnt[n]);
     return 0;
 }

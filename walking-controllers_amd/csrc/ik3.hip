@@ -451,6 +451,8 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const int max_iter = prm->max_iter;
     double lo0 = prm->vlo[j], hi0 = prm->vhi[j], lo1 = prm->vlo[col1], hi1 = prm->vhi[col1];
     // ---------------- phase 4: Hr^-1 (sweep over the NN pivots), x_N, x_B -------------------------
+    // (a variant that hands lane k's row to the others by DPP row_newbcast - no LDS instruction, 28 VALU
+    // moves per pivot - measured 3 % slower on the whole kernel: the phase is issue-bound)
     {
         double* col = S + OFF_COL;
         col[j] = Hr[0];

@@ -67,6 +67,14 @@ __device__ __forceinline__ void rows_pair(double v, double& d0, double& d1) {
     d0 = __hiloint2double((int)rh[0], (int)rl[0]);
     d1 = __hiloint2double((int)rh[1], (int)rl[1]);
 }
+// Value of lane SRC of each 16-lane DPP row on every lane of that row: DPP row_newbcast (gfx90a+),
+// one VALU move per dword, no LDS pipe.  SRC must be a compile-time constant.
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + (SRC & 15), 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + (SRC & 15), 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 // all-reduce over the 32 lanes of a group: four DPP steps inside each row of 16 (xor 1, xor 2 as
 // quad permutes; then half-mirror and mirror, which pair up quads / octets that already agree),
 // one row exchange between the two rows
