@@ -40,7 +40,7 @@ constexpr int OFF_P = 15 * LDF;       // 270
 //   set-up
 constexpr int OFF_ST = OFF_P;         // [112] state + q (dead after the gradient)
 constexpr int OFF_CB = OFF_P + 112;   // [4][16] entries of a panel's 4 pivot columns; before that the task rhs b
-constexpr int OFF_RD = OFF_P + 176;   // [16][8] per row r: {D, g, neck-row entries} of its basic variable
+constexpr int OFF_RD = OFF_P + 176;   // [16][8] per row r: {g, 3 neck-row entries, D} of its basic variable
 constexpr int OFF_GRV = OFF_P + 304;  // [16] reduced gradient by compact index
 constexpr int OFF_DN = OFF_P + 320;   // [16] Lambda entry of the free variable with compact index k
 constexpr int OFF_YTT = OFF_P;        // [5][16] rows 15..19 of Y^T: (W N Z)' and zero padding  (over ST)
@@ -340,11 +340,11 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     double* rd = S + OFF_RD;
     if (!free0) {
         double* d = rd + myrow0 * 8;
-        d[0] = Di0; d[1] = g0; d[2] = cn0[0]; d[3] = cn0[1]; d[4] = cn0[2];
+        d[0] = g0; d[1] = cn0[0]; d[2] = cn0[1]; d[3] = cn0[2]; d[4] = Di0;
     }
     if (var1 && !free1) {
         double* d = rd + myrow1 * 8;
-        d[0] = Di1; d[1] = g1; d[2] = cn1[0]; d[3] = cn1[1]; d[4] = cn1[2];
+        d[0] = g1; d[1] = cn1[0]; d[2] = cn1[1]; d[3] = cn1[2]; d[4] = Di1;
     }
     if (free0) {
 #pragma unroll
@@ -364,13 +364,12 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     double gr0 = g0, gr1 = g1;
 #pragma unroll
     for (int r = 0; r < MEQ; ++r) {
-        const double2 dg = *reinterpret_cast<const double2*>(rd + r * 8);
-        const double2 n01 = *reinterpret_cast<const double2*>(rd + r * 8 + 2);
-        const double n2 = rd[r * 8 + 4];
-        nz0[0] = fma(-n01.x, a0[r], nz0[0]); nz0[1] = fma(-n01.y, a0[r], nz0[1]); nz0[2] = fma(-n2, a0[r], nz0[2]);
-        nz1[0] = fma(-n01.x, a1[r], nz1[0]); nz1[1] = fma(-n01.y, a1[r], nz1[1]); nz1[2] = fma(-n2, a1[r], nz1[2]);
-        gr0 = fma(-a0[r], dg.y, gr0);
-        gr1 = fma(-a1[r], dg.y, gr1);
+        const double2 gn = *reinterpret_cast<const double2*>(rd + r * 8);          // {g, n0}
+        const double2 nn = *reinterpret_cast<const double2*>(rd + r * 8 + 2);      // {n1, n2}
+        nz0[0] = fma(-gn.y, a0[r], nz0[0]); nz0[1] = fma(-nn.x, a0[r], nz0[1]); nz0[2] = fma(-nn.y, a0[r], nz0[2]);
+        nz1[0] = fma(-gn.y, a1[r], nz1[0]); nz1[1] = fma(-nn.x, a1[r], nz1[1]); nz1[2] = fma(-nn.y, a1[r], nz1[2]);
+        gr0 = fma(-a0[r], gn.x, gr0);
+        gr1 = fma(-a1[r], gn.x, gr1);
         if ((r & 3) == 3) wcqp::pin_result(gr0);
     }
     wcqp::wave_lds_fence();           // ST / CB are dead: the operand tails overlay them
@@ -416,7 +415,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             const bool tail = kk >= MEQ;
             const int oy = tail ? OFF_YTT + (kk - MEQ) * 16 + mk : OFF_F + kk * LDF + mk;
             const int ox = tail ? OFF_XTT + (kk - MEQ) * 16 + mk : OFF_F + kk * LDF + mk;
-            const int od = tail ? OFF_RD : OFF_RD + kk * 8;
+            const int od = tail ? OFF_RD + 4 : OFF_RD + kk * 8 + 4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const double yv = smem[g][oy];
