@@ -538,13 +538,11 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         double* Rinv = S + OFF_RINV;
         double* tpb = S + OFF_TPB;
         double* zb = S + OFF_ZB;
-        double* sv = S + OFF_SV;
         double* rvec = S + OFF_RV;
         double* cvec = S + OFF_CV;
         double* tkb = S + OFF_TKB;
         double* tbv = S + OFF_TBV;
         int* Wi = reinterpret_cast<int*>(S + OFF_WI);
-        int* info = reinterpret_cast<int*>(S + OFF_INFO);
         bool s_live = false;
         int s_var = 0;
         double s_sg = 0.0, s_mu = 0.0;
@@ -556,7 +554,24 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         bool pending = false;
         int p = 0;
         double sig = 0.0, s = 0.0, tp0 = 0.0, tp1 = 0.0, ppp = 1.0, mu_p = 0.0;
+        int p_info = 0;                 // entering column: compact index if free, 32 + row if basic
         bool done = false;
+        // Working sets of up to KS bounds are kept REPLICATED on every lane of the instance (uniform inside
+        // the DPP row): variable, sign, multiplier, the explicit inverse Rs of the active-bound system.
+        // The dual step, the Schur complement and the ratio test are then plain register arithmetic
+        // (k^2 FMAs, no slot-lane exchange, no reduction, no LDS), and a working-set drop costs no LDS
+        // trip at all; only tau_p itself still travels through LDS.  Bigger working sets fall back to the
+        // slot-per-lane loop below.
+        constexpr int KS = 4;
+        // (Rs is symmetric: only b >= a is stored and updated; a slot is live iff its sign is not 0)
+        double Rs[KS][KS], sgS[KS], muS[KS], tvS[KS];
+        int wS[KS], infoS[KS];
+#pragma unroll
+        for (int a = 0; a < KS; ++a) {
+            sgS[a] = 0.0; muS[a] = 0.0; tvS[a] = 0.0; wS[a] = 0; infoS[a] = 0;
+#pragma unroll
+            for (int b = 0; b < KS; ++b) Rs[a][b] = 0.0;
+        }
         // key of the most violated bound outside the working set (0: none); the choice runs on float
         // keys, the value itself is read back exactly from the owner
         auto most_violated = [&]() -> unsigned {
@@ -571,34 +586,36 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         auto enter = [&](unsigned key) {
             ++it;
             p = 31 - (int)(key & 31u);
-            if (p == j) {
-                const double vh = nu0 - hi0, vl = lo0 - nu0;
-                sv[0] = fmax(vh, vl); sv[1] = vh >= vl ? 1.0 : -1.0; info[0] = free0 ? 0 : 1; info[1] = free0 ? kap0 : myrow0;
-            }
-            if (p == col1) {
-                const double vh = nu1 - hi1, vl = lo1 - nu1;
-                sv[0] = fmax(vh, vl); sv[1] = vh >= vl ? 1.0 : -1.0; info[0] = free1 ? 0 : 1; info[1] = free1 ? kap1 : myrow1;
-            }
-            wcqp::wave_lds_fence();
-            s = sv[0];
-            sig = sv[1];
-            const bool p_basic = info[0] != 0;
-            const int p_idx = info[1];
-            if (!p_basic && j == p_idx) {
-#pragma unroll
-                for (int k = 0; k < NN; k += 2) *reinterpret_cast<double2*>(tkb + k) = make_double2(-Hr[k], -Hr[k + 1]);   // row == column
-            }
+            // the owner lane's signed violation and (free / basic, index) of column p: every lane prepares
+            // the values of its slot p >> 4, ds_bpermute fetches lane p & 15's (no stores, no branches)
+            const bool sl1 = p >= 16;
+            const double vh = sl1 ? nu1 - hi1 : nu0 - hi0, vl = sl1 ? lo1 - nu1 : lo0 - nu0;
+            const double sviol = vh >= vl ? vh : -vl;                                   // sign = side, |.| = violation
+            const int myinfo = sl1 ? (free1 ? kap1 : 32 + myrow1) : (free0 ? kap0 : 32 + myrow0);
+            const int src = ((lane & 48) + (p & 15)) << 2;
+            const double sv_p = lane_gather(sviol, src);
+            p_info = __builtin_amdgcn_ds_bpermute(src, myinfo);
+            s = fabs(sv_p);
+            sig = sv_p >= 0.0 ? 1.0 : -1.0;
+            const bool p_basic = p_info >= 32;
+            const int p_idx = p_basic ? p_info - 32 : p_info;
+            // t = Hr^-1 Z' e_p by compact index: column p_idx of the inverse (= entry p_idx of this lane's
+            // row, picked by a select chain: the index is uniform in the row but not a constant), or
+            // -Hinv F[row_p,:]' for a basic variable
+            double t = 0.0;
             if (p_basic) {
                 const double* frow = F + p_idx * LDF;
-                double t = 0.0;
 #pragma unroll
                 for (int k = 0; k < NN; k += 2) {
                     const double2 f2 = *reinterpret_cast<const double2*>(frow + k);
                     t = fma(Hr[k], f2.x, t);
                     t = fma(Hr[k + 1], f2.y, t);
                 }
-                tkb[j] = t;                                          // -Hinv F[row_p,:]'  (lanes >= NN: 0)
+            } else {
+#pragma unroll
+                for (int k = 0; k < NN; ++k) t = (k == p_idx) ? -Hr[k] : t;
             }
+            tkb[j] = t;                                                  // lanes >= NN: 0
             wcqp::wave_lds_fence();
             {
                 const double* frow = F + (j < MEQ ? j : 0) * LDF;
@@ -616,7 +633,10 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             tp0 = sig * (free0 ? tkb[kap0] : tbv[myrow0]);
             tp1 = var1 ? sig * (free1 ? tkb[kap1] : tbv[myrow1]) : 0.0;
             ppp = p_basic ? tbv[p_idx] : tkb[p_idx];                 // P[p][p] > 0 (sig * sig * tau_p[p])
-            tpb[j] = tp0; tpb[col1] = tp1;                           // read by the slot lanes when nW > 0
+            // tau_p at the variables of the replicated working set (slots that are not live read entry 0)
+#pragma unroll
+            for (int a = 0; a < KS; ++a) tvS[a] = (infoS[a] < 32) ? tkb[infoS[a]] : tbv[infoS[a] - 32];
+            tpb[j] = tp0; tpb[col1] = tp1;                           // read by the slot lanes of the general loop
             mu_p = 0.0;
             pending = true;
         };
@@ -630,10 +650,8 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double t = s * inz;
                 nu0 = fma(-t, tp0, nu0);
                 nu1 = fma(-t, tp1, nu1);
-                // (Rinv and the other slots' columns are only set up if the general loop is entered)
-                if (j == 0) { s_live = true; s_var = p; s_sg = sig; s_mu = t; Wi[0] = p; }
+                wS[0] = p; infoS[0] = p_info; sgS[0] = sig; muS[0] = t; Rs[0][0] = inz;
                 tc0[0] = tp0; tc1[0] = tp1;
-                ppp = inz;                                 // = Rinv[0][0], kept for that set-up
                 if (p == j) { in_w0 = true; sig0 = sig; }
                 if (p == col1) { in_w1 = true; sig1 = sig; }
                 nW = 1;
@@ -645,12 +663,126 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             }
         }
         WCQP_STAMP(14);
-        if (!done) {
 #pragma unroll
-            for (int a = 1; a < KMAX; ++a) { tc0[a] = 0.0; tc1[a] = 0.0; }
+        for (int a = 1; a < KS; ++a) { tc0[a] = 0.0; tc1[a] = 0.0; }
+        bool small = !done;
+#pragma unroll 1
+        for (int pass = 0; pass < 1024 && small; ++pass) {
+            if (!pending) {
+                if (nW >= KS) { small = false; break; }                      // a fifth bound: general loop
+                const unsigned key = most_violated();
+                if (key == 0u) { done = true; small = false; break; }
+                if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; small = false; break; }
+                enter(key);
+            }
+            // dual step r = Rs c with c_a = sigma_a sigma_p tau_p[w_a]; primal step z = tp - sum_a r_a Tc[a];
+            // Schur complement of the bordered system = P[p][p] - r'c (P is symmetric)
+            double c[KS], r[KS];
+#pragma unroll
+            for (int a = 0; a < KS; ++a) c[a] = sgS[a] * sig * tvS[a];       // 0 on slots that are not live
+            double z0 = tp0, z1 = tp1, nzv = ppp, t1 = inf;
+            int jd = 0;
+#pragma unroll
+            for (int a = 0; a < KS; ++a) {
+                double ra = 0.0;
+#pragma unroll
+                for (int b = 0; b < KS; ++b) ra = fma(b >= a ? Rs[a][b] : Rs[b][a], c[b], ra);
+                r[a] = ra;
+                z0 = fma(-ra, tc0[a], z0);
+                z1 = fma(-ra, tc1[a], z1);
+                nzv = fma(-ra, c[a], nzv);
+            }
+#pragma unroll
+            for (int a = 0; a < KS; ++a) {
+                const double ratio = (sgS[a] != 0.0 && r[a] > 0.0) ? muS[a] * wcqp::fast_rcp(r[a]) : inf;
+                if (ratio < t1) { t1 = ratio; jd = a; }                      // ties: lowest slot
+            }
+            const double inz = wcqp::fast_rcp(nzv);
+            const double t2 = (nzv > 1e-10 * ppp) ? s * inz : inf;           // dependence shows as a vanishing Schur complement
+            const double t = fmin(t1, t2);
+            if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; done = true; small = false; break; }
+            nu0 = fma(-t, z0, nu0);
+            nu1 = fma(-t, z1, nu1);
+#pragma unroll
+            for (int a = 0; a < KS; ++a) muS[a] = fma(-t, r[a], muS[a]);      // r = 0 on slots that are not live
+            mu_p += t;
+            s -= t * nzv;
+            if (t2 <= t1) {
+                // full step: p takes the first free slot n; Rs <- bordered inverse
+                int n = KS - 1;
+#pragma unroll
+                for (int a = KS - 1; a >= 0; --a) n = (sgS[a] != 0.0) ? n : a;
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    const bool me = a == n;
+                    const double ra_inz = r[a] * inz;
+#pragma unroll
+                    for (int b = a; b < KS; ++b) {
+                        // r[n] = 0 (the slot was empty), so the plain update leaves row / column n alone and the
+                        // border is one select per entry
+                        const double upd = fma(ra_inz, r[b], Rs[a][b]);
+                        Rs[a][b] = (b == n) ? (me ? inz : -ra_inz) : (me ? -r[b] * inz : upd);
+                    }
+                    wS[a] = me ? p : wS[a];
+                    infoS[a] = me ? p_info : infoS[a];
+                    sgS[a] = me ? sig : sgS[a];
+                    muS[a] = me ? mu_p : muS[a];
+                    tc0[a] = me ? tp0 : tc0[a];
+                    tc1[a] = me ? tp1 : tc1[a];
+                }
+                if (p == j) { in_w0 = true; sig0 = sig; }
+                if (p == col1) { in_w1 = true; sig1 = sig; }
+                ++nW;
+                pending = false;
+            } else {
+                // partial step: slot jd leaves the working set; Rs <- downdated inverse.  The same entering
+                // bound stays pending and the next pass needs nothing from LDS.
+                int wdrop = 0;
+                double cj[KS];
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    wdrop = (a == jd) ? wS[a] : wdrop;
+                    cj[a] = 0.0;
+#pragma unroll
+                    for (int b = 0; b < KS; ++b) cj[a] = (b == jd) ? (b >= a ? Rs[a][b] : Rs[b][a]) : cj[a];   // column jd
+                }
+                double djj = 1.0;
+#pragma unroll
+                for (int a = 0; a < KS; ++a) djj = (a == jd) ? cj[a] : djj;
+                const double idj = wcqp::fast_rcp(djj);
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    const bool me = a == jd;
+                    const double fa = cj[a] * idj;
+#pragma unroll
+                    for (int b = a; b < KS; ++b) Rs[a][b] = (me || b == jd) ? 0.0 : fma(-fa, cj[b], Rs[a][b]);
+                    sgS[a] = me ? 0.0 : sgS[a];
+                    muS[a] = me ? 0.0 : muS[a];
+                }
+                if (wdrop == j) { in_w0 = false; sig0 = 0.0; }
+                if (wdrop == col1) { in_w1 = false; sig1 = 0.0; }
+                --nW;
+                ++it;
+            }
+        }
+        if (!done) {
+            // hand-over to the slot-per-lane representation: lane a owns slot a, row a of the inverse goes to LDS
+#pragma unroll
+            for (int a = KS; a < KMAX; ++a) { tc0[a] = 0.0; tc1[a] = 0.0; }
+            double myrow[KS];
+#pragma unroll
+            for (int b = 0; b < KS; ++b) {
+                myrow[b] = 0.0;
+#pragma unroll
+                for (int a = 0; a < KS; ++a) myrow[b] = (a == j) ? (b >= a ? Rs[a][b] : Rs[b][a]) : myrow[b];
+            }
+#pragma unroll
+            for (int a = 0; a < KS; ++a) {
+                if (a == j) { s_live = sgS[a] != 0.0; s_var = wS[a]; s_sg = sgS[a]; s_mu = muS[a]; Wi[a] = wS[a]; }
+            }
             if (j < KMAX) {
 #pragma unroll
-                for (int b = 0; b < KMAX; ++b) myR[b] = (j == 0 && b == 0) ? ppp : 0.0;
+                for (int b = 0; b < KMAX; ++b) myR[b] = (b < KS) ? myrow[b < KS ? b : 0] : 0.0;
             }
             wcqp::wave_lds_fence();
         }
