@@ -205,7 +205,7 @@ def main():
             "parallelism": "batch sharded over %d GPU(s), no data-path collective%s" % (world, " + RCCL scatter/gather" if exch else ""),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "ik3_kernel" if B >= 4096 else "ik2_kernel<true,true>",
+            "bound": "hbm", "kernel": "ik3_kernel",
             "achieved": IK_BYTES_PER_QP * B / (ik_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": IK_BYTES_PER_QP * B / (ik_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": ik_ms, "algorithmic_bytes_per_launch": IK_BYTES_PER_QP * B,

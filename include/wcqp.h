@@ -153,11 +153,11 @@ int wcqp_hull_from_feet_host(int32_t batch, const double* foot_rect,
 #define WCQP_IK_ALG_SWEEP     1
 #define WCQP_IK_ALG_NULLSPACE 2        /* null-space kernel, reduced Hessian on the fp64 VALU                 */
 #define WCQP_IK_ALG_NULLSPACE_MFMA 3   /* same, reduced-Hessian Gram product as one v_mfma_f64_16x16x4 tile per
-                                          instance: ~5 % faster than 2 in interleaved A/B runs (the default below batch 4096);
+                                          instance: ~5 % faster than 2 in interleaved A/B runs;
                                           needs use_com_as_constraint (one 16x16 tile), else runs as 2        */
 #define WCQP_IK_ALG_NULLSPACE_16L 4    /* null-space kernel on 16 lanes per instance, 4 instances per wave
-                                          (csrc/ik3.hip): 1.3x the throughput of 3 on a full chip (the default from batch
-                                          4096 up); needs use_com_as_constraint, else runs as 2                 */
+                                          (csrc/ik3.hip): 1.6x the throughput of 3 on a full chip, ahead at every batch
+                                          size (the default); needs use_com_as_constraint, else runs as 2       */
 #define WCQP_IK_FORM_OSQP    1   /* joint-limit rows are zero rows (never bind), extra
                                     k_attFoot on the neck gradient term, zero-twist rule
                                                                */
@@ -177,7 +177,7 @@ typedef struct wcqp_ik_params {
     double  k_pos_com, k_pos_foot, k_att_foot, k_neck;
     double  rho;                         /* weight of the A'A term that regularises H; 0 -> 1  */
     double  tol;                         /* bound-violation tolerance; 0 -> 1e-12              */
-    int32_t algorithm;                   /* WCQP_IK_ALG_*: 0 -> default (4 for batch >= 4096, else 3), 1 = sweep on H + rho A'A (csrc/ik.hip),
+    int32_t algorithm;                   /* WCQP_IK_ALG_*: 0 -> default (4; 2 for CoM-as-cost), 1 = sweep on H + rho A'A (csrc/ik.hip),
                                             2 / 3 = null-space (csrc/ik2.hip) without / with MFMA, 4 = null-space on
                                             16 lanes per instance (csrc/ik3.hip); same optimum */
 } wcqp_ik_params;

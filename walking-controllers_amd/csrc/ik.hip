@@ -494,10 +494,9 @@ int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
     if (batch == 0) return WCQP_OK;
     const int rc = ensure_device(h);
     if (rc != WCQP_OK) return rc;
-    // default: 16 lanes per instance once the batch fills the chip (>= 1 wave per SIMD either way),
-    // 32 lanes per instance below that, where only the latency of a single wave counts
-    // (measured cross-over at batch ~4096: profiles/r01_ik_batch_sweep.json)
-    const bool use16 = h->p.algorithm == WCQP_IK_ALG_NULLSPACE_16L || (h->p.algorithm == WCQP_IK_ALG_DEFAULT && batch >= 4096);
+    // default: the 16-lanes-per-instance kernel (fastest at every batch size measured, 64 .. 65536:
+    // profiles/r01_ik_batch_sweep.json); it needs the CoM-as-constraint form (14 free variables + rhs <= 16 lanes)
+    const bool use16 = h->p.algorithm == WCQP_IK_ALG_NULLSPACE_16L || h->p.algorithm == WCQP_IK_ALG_DEFAULT;
     if (use16 && h->p.use_com_as_constraint)
         return wcqp_ik::ik3_launch(h->d_prm, batch, J_left, J_right, J_neck, J_com, q, state, dq, status,
                                    active_lower, active_upper, foot_err, iters, (hipStream_t)stream);

@@ -58,11 +58,9 @@ constexpr int OFF_CV = OFF_P + 292;   // [16]
 constexpr int OFF_TKB = OFF_P + 308;  // [16] t by compact index
 constexpr int OFF_TBV = OFF_P + 324;  // [16] -F t by row
 constexpr int OFF_WI = OFF_P + 340;   // [16] ints: variable of slot a
-constexpr int OFF_INFO = OFF_P + 348; // [4] ints
-constexpr int OFF_SV = OFF_P + 350;   // [2] violation and sign of the entering bound
 constexpr int P_SIZE = 352;
 constexpr int PER_INST = 632;         // >= OFF_P + P_SIZE = 622, = 24 mod 32
-static_assert(OFF_DN + 16 <= OFF_P + P_SIZE && OFF_HM + 16 * LDH <= OFF_GRV && OFF_P + P_SIZE <= PER_INST, "LDS overlays");
+static_assert(OFF_WI + 8 <= OFF_P + P_SIZE && OFF_DN + 16 <= OFF_P + P_SIZE && OFF_HM + 16 * LDH <= OFF_GRV && OFF_P + P_SIZE <= PER_INST, "LDS overlays");
 static_assert(PER_INST % 32 == 24 || PER_INST % 32 == 8, "instances 16 banks apart");
 static_assert(PER_INST * 8 * 4 * 8 <= 160 * 1024, "8 blocks per CU");
 
