@@ -452,6 +452,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     // moves per pivot - measured 3 % slower on the whole kernel: the phase is issue-bound)
     {
         double* col = S + OFF_COL;
+        double pmin = 1.0;
         col[j] = Hr[0];
         wcqp::wave_lds_fence();
 #pragma unroll
@@ -459,7 +460,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             double* cb = col + 16 * (k & 1);
             double* nb = col + 16 * ((k + 1) & 1);
             const double piv = cb[k];
-            ok = ok && (piv > 0.0);
+            pmin = (piv > 0.0) ? pmin : -1.0;   // NaN-safe flag carried in a register: hipcc otherwise keeps all 14 pivots alive to test them at the end
             const double d = wcqp::fast_rcp(piv);
             const double f0 = Hr[k] * d;
             const double f = (j == k) ? (1.0 - d) : f0;
@@ -476,6 +477,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             Hr[k] = (j == k) ? -d : f0;
             wcqp::wave_lds_fence();
         }
+        ok = ok && (pmin > 0.0);
     }
     WCQP_STAMP(6);
     // Hr now holds row j of -(Hr^-1) on lanes j < NN
