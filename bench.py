@@ -159,7 +159,7 @@ def main():
         if ev is not None:
             ev[0].record(stream)
         launch_ik()
-        if ev is not None:
+        if ev is not None and not two_streams:
             ev[1].record(stream)
         if exch:
             exch[1]()
@@ -174,7 +174,9 @@ def main():
         step()
     barrier()
     # HIP events around the IK launch of every `stride`-th timed step (a pair of event records costs about
-    # as much as a launch, so bracketing every step would slow the thing being measured)
+    # as much as a launch, so bracketing every step would slow the thing being measured).  With two streams
+    # the IK stream carries nothing but IK launches: one event every `stride` steps, and the kernel's
+    # average duration is the time between consecutive events / stride (inter-launch gap included).
     stride = max(1, int(os.environ.get("WCQP_BENCH_EVENT_STRIDE", str(max(1, min(8, args.steps // 8))))))
     events = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, stride)}
     t0 = time.perf_counter()
@@ -183,7 +185,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(dist, torch, dev, elapsed)
-    ik_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))      # IK kernel, HIP events on its stream
+    if two_streams and len(events) >= 2:
+        keys = sorted(events)
+        ik_ms = float(np.mean([events[a][0].elapsed_time(events[b][0]) / (b - a) for a, b in zip(keys[:-1], keys[1:])]))
+    else:
+        ik_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))      # IK kernel, HIP events on its stream
     # MPC kernel duration: a short separately timed run (it is not the dominant kernel)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
