@@ -262,8 +262,11 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 wcqp::pin_value(myrow1);
                 double c[4];
                 const int src = (rowbase + (p & 15)) << 2;
+                // 1 / pivot and the entry of the next pivot row first: they are what the next arg-max waits for
+                c[s] = lane_gather(m[s], src);
+                if (s + 1 < pw) c[s + 1] = lane_gather(m[s + 1], src);
 #pragma unroll
-                for (int u = 0; u < pw; ++u) c[u] = lane_gather(m[u], src);
+                for (int u = 0; u < pw; ++u) { if (u != s && u != s + 1) c[u] = lane_gather(m[u], src); }
                 const double t0 = a0[r] * c[s], t1 = a1[r] * c[s];
 #pragma unroll
                 for (int u = 0; u < pw; ++u) {
