@@ -98,8 +98,11 @@ __device__ __forceinline__ unsigned mag_key(double v) { return __float_as_uint((
 // TICK: the receding-horizon pipeline's glue (ZMP-CoM law, plant; tick_device.h) runs in the prologue
 // and its post step (joint integration, next contact pair, tick counter) in the epilogue, so that a
 // tick is two launches (MPC, this) instead of four.
+#ifndef WCQP_IK3_WAVES
+#define WCQP_IK3_WAVES 2
+#endif
 template <bool TICK>
-__global__ __launch_bounds__(64, 2)
+__global__ __launch_bounds__(64, WCQP_IK3_WAVES)
 void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
                 const double* __restrict__ JN, const double* __restrict__ JC,
