@@ -227,6 +227,9 @@ def main():
         },
         "kernels": {
             "ik_ms": ik_ms, "ik_qps_per_gpu": B / (ik_ms * 1e-3),
+            # secondary bound: ~30 kflop per IK-QP (elimination 13.5 k, Gram product 8.1 k, sweep 5.5 k,
+            # tables / x / active set ~3 k) against the 78.6 TFLOP/s fp64 vector peak
+            "ik_fp64_tflops": 30e3 * B / (ik_ms * 1e-3) / 1e12, "ik_fp64_frac": 30e3 * B / (ik_ms * 1e-3) / 78.6e12,
             "mpc_ms": mpc_ms, "mpc_qps_per_gpu": B / (mpc_ms * 1e-3),
             "mpc_hbm_frac": MPC_BYTES_PER_QP * B / (mpc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         },
