@@ -241,8 +241,10 @@ int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
  *         velocity into the IK pose block (WalkingModule.cpp:686-695); synthetic LIPM plant
  *   IK    joint velocities
  *   post  q <- Integrator(dq) (WalkingModule.cpp:741-744), contact pair of the next tick, tick += 1
- * The four launches of a tick are captured ONCE in a hipGraph and replayed per tick
- * (`use_graph`), with the tick index living in device memory.
+ * With the default IK kernel the glue and post steps run inside the IK kernel (two launches per
+ * tick: MPC, IK); an explicit 32-lane / sweep IK algorithm or the CoM-as-cost variant keeps them as
+ * stand-alone kernels (four launches).  `use_graph` replays hipGraphs of 8 ticks each (captured
+ * ONCE: the tick index lives in device memory), remaining ticks go as plain launches.
  * ===================================================================================== */
 typedef struct wcqp_tick_params {
     int32_t batch;              /* instances on this device                                   */
