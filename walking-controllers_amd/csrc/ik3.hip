@@ -10,7 +10,10 @@
 //   * an instance is one DPP row: every reduction is 4 DPP steps, no row exchange;
 //   * the reduced Hessian row k lives on lane k (k = compact index), not on the variable's lane;
 //   * the Gram product is one fp64 MFMA tile per instance, X' = D_B F formed on the fly.
-// LDS is 640 doubles per instance (20 KB per block: 8 blocks per CU = the whole 160 KB).
+//   * bounds: Goldfarb-Idnani dual active set; first bound straight-line, working sets of up to 4 bounds
+//     replicated in registers, larger ones slot-per-lane (see phase 5).
+// LDS is 632 doubles per instance (20.2 KB per block: 8 blocks per CU); the default IK kernel of the library.
+// Template parameter TICK: the tick pipeline's glue / post steps fused in (tick_device.h).
 #include <cmath>
 #include <limits>
 #include "ik_common.h"
