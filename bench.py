@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--ik-vmax", type=float, default=0.5, help="joint velocity limit of the synthetic robots [rad/s]")
     ap.add_argument("--ik-form", choices=["qpoases", "osqp"], default="qpoases")
     ap.add_argument("--exchange", action="store_true", help="RCCL scatter inputs / gather solutions every step")
-    ap.add_argument("--workload", choices=["qp", "tick"], default="qp",
+    ap.add_argument("--workload", choices=["qp", "tick", "kin"], default="qp",
                     help="qp: configs[1]+[2] cold-start batches (default); tick: the device-resident receding-horizon "
                          "MPC->glue->IK tick of configs[3]/[4], one hipGraph replay per step")
     ap.add_argument("--no-graph", action="store_true", help="tick workload: plain launches instead of hipGraph replay")
@@ -87,6 +87,8 @@ def main():
     first = rank * B
     if args.workload == "tick":
         return bench_tick(args, wca, torch, dist, dev, world, rank, B, first)
+    if args.workload == "kin":
+        return bench_kin(args, wca, torch, dist, dev, world, rank, B, first)
     # ---- synthetic inputs (each rank generates its own shard: identical to the rows a rank-0
     # scatter would hand it, walking-controllers_amd/synth.py is counter-based) -------------
     mb = wca.synth.synth_mpc_batch(B, seed=1234, first=first)
@@ -261,6 +263,56 @@ def max_over_ranks(dist, torch, dev, value):
     t = torch.tensor([value], dtype=torch.float64, device=on)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def bench_kin(args, wca, torch, dist, dev, world, rank, B, first):
+    """Auxiliary line: the kinematics kernel alone - Jacobians and poses of B robots per step.
+    Not the BASELINE metric: `metric` says so; the roofline is the kernel's own (HBM: it is bound by the 4.4 KB it
+    writes per robot)."""
+    kb = wca.synth.synth_kin_batch(B, first=first)
+    kin = wca.KinModel(wca.synth.icub_like_model())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    base, q = t(kb["base"]), t(kb["q"])
+    JL = torch.zeros(B, 6, 29, dtype=torch.float64, device=dev); JR = torch.zeros_like(JL)
+    JN = torch.zeros(B, 3, 29, dtype=torch.float64, device=dev); JC = torch.zeros_like(JN)
+    state = torch.zeros(B, 87, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        kin.jacobians_device(B, base.data_ptr(), q.data_ptr(), JL.data_ptr(), JR.data_ptr(), JN.data_ptr(), JC.data_ptr(),
+                             state.data_ptr(), stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    barrier()
+    elapsed = max_over_ranks(dist, torch, dev, time.perf_counter() - t0)
+    k_ms = e0.elapsed_time(e1) / args.steps
+    bytes_per = 12 * 8 + 23 * 8 + (6 + 6 + 3 + 3) * 29 * 8 + 36 * 8           # base + q in; Jacobians + actual poses out
+    out = {
+        "metric": "robots/sec through the kinematics kernel (auxiliary; NOT the BASELINE metric)",
+        "value": B * world * args.steps / elapsed, "unit": "robots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "forward kinematics + MIXED free-floating Jacobians (2 feet, neck, CoM) of an iCub-shaped 23-DoF tree, B=%d" % B,
+                   "batch_per_gpu": B, "global_batch": B * world, "dof": 23},
+        "roofline": {"bound": "hbm", "kernel": "kin_jacobians_kernel", "achieved": bytes_per * B / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": bytes_per * B / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per * B},
+    }
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):

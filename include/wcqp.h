@@ -228,6 +228,49 @@ int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
                        double* foot_err, int32_t* iters);
 
 /* =====================================================================================
+ * Batched kinematics: forward kinematics of a kinematic tree and the free-floating
+ * Jacobians in MIXED representation that the QP-IK consumes - what the reference obtains from
+ * iDynTree::KinDynComputations through WalkingFK:
+ *   setInternalRobotState        WM/src/WalkingForwardKinematics.cpp:258-276
+ *   get{Left,Right}FootToWorldTransform, getNeckOrientation, getCoMPosition   :312-340, 354-366, 402-405
+ *   get{Left,Right}FootJacobian, getNeckJacobian, getCoMJacobian              :436-454 (MIXED, :33)
+ * The robot model of the reference is an external URDF (WalkingModule.cpp:107) that is not in the
+ * repository: the tree comes in as a table.  Joint j has a parent joint (-1 = root link, always < j), a
+ * fixed transform (R0, p0) from the parent joint frame to its own frame at q = 0, a unit axis in its own
+ * frame and carries one link; three frames are attached: left sole, right sole, neck.
+ * Generalised velocity: (v of the base origin in world, omega of the base in world, dq).
+ * Outputs use the batch layouts of wcqp_ik_solve_*: J_left/J_right [B][6][6+dof] (linear rows, then
+ * angular), J_neck [B][3][6+dof] (angular rows), J_com [B][3][6+dof]; if `state` is given, the ACTUAL
+ * poses are written into the packed pose block (foot positions/rotations, neck rotation, CoM position:
+ * offsets 0..23, 48..56, 66..68), the desired entries are left alone.
+ * ===================================================================================== */
+#define WCQP_KIN_MAX_DOF 32
+typedef struct wcqp_kin_params {
+    int32_t dof;                        /* 6 + dof <= 32                                          */
+    int32_t parent[WCQP_KIN_MAX_DOF];   /* parent joint, -1 = root link; parent[j] < j             */
+    double  R0[WCQP_KIN_MAX_DOF][9];    /* row-major                                               */
+    double  p0[WCQP_KIN_MAX_DOF][3];
+    double  axis[WCQP_KIN_MAX_DOF][3];  /* in the joint's own frame; normalised at create          */
+    double  mass[WCQP_KIN_MAX_DOF];     /* link carried by joint j                                 */
+    double  com[WCQP_KIN_MAX_DOF][3];   /* its centre of mass in the joint frame                   */
+    double  root_mass, root_com[3];
+    int32_t frame_joint[3];             /* left sole, right sole, neck: joint the frame is fixed to */
+    double  frame_R[3][9], frame_p[3][3];
+} wcqp_kin_params;
+
+typedef struct wcqp_kin_s* wcqp_kin_t;
+
+int wcqp_kin_create(const wcqp_kin_params* params, wcqp_kin_t* out);
+int wcqp_kin_destroy(wcqp_kin_t h);
+/* base [B][12] = position, row-major rotation of the root link; q [B][dof].  DEVICE pointers. */
+int wcqp_kin_jacobians_device(wcqp_kin_t h, int32_t batch, const double* base, const double* q,
+                              double* J_left, double* J_right, double* J_neck, double* J_com,
+                              double* state /* [B][87] or NULL */, void* stream);
+/* same with HOST pointers (copies in and out; `state` is read-modify-write) */
+int wcqp_kin_jacobians_host(wcqp_kin_t h, int32_t batch, const double* base, const double* q,
+                            double* J_left, double* J_right, double* J_neck, double* J_com, double* state);
+
+/* =====================================================================================
  * Device-resident tick pipeline — BASELINE configs 4/5 and SURVEY.md §8f-1/2: the call
  * order of WalkingModule::updateModule around the two solvers (WM/src/WalkingModule.cpp:
  * 578-745) for a batch of synthetic robots, kept entirely on the GPU:

@@ -32,6 +32,7 @@ ABI_SYMBOLS = (
     "wcqp_mpc_solve_device", "wcqp_mpc_solve_host",
     "wcqp_ik_create", "wcqp_ik_destroy", "wcqp_ik_solve_device", "wcqp_ik_solve_host",
     "wcqp_hull_from_feet_device", "wcqp_hull_from_feet_host",
+    "wcqp_kin_create", "wcqp_kin_destroy", "wcqp_kin_jacobians_device", "wcqp_kin_jacobians_host",
     "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download",
 )
 
@@ -56,6 +57,14 @@ class IkParams(C.Structure):
                 ("k_pos_com", C.c_double), ("k_pos_foot", C.c_double),
                 ("k_att_foot", C.c_double), ("k_neck", C.c_double),
                 ("rho", C.c_double), ("tol", C.c_double), ("algorithm", C.c_int32)]
+
+
+class KinParams(C.Structure):
+    _fields_ = [("dof", C.c_int32), ("parent", C.c_int32 * 32),
+                ("R0", (C.c_double * 9) * 32), ("p0", (C.c_double * 3) * 32), ("axis", (C.c_double * 3) * 32),
+                ("mass", C.c_double * 32), ("com", (C.c_double * 3) * 32),
+                ("root_mass", C.c_double), ("root_com", C.c_double * 3),
+                ("frame_joint", C.c_int32 * 3), ("frame_R", (C.c_double * 9) * 3), ("frame_p", (C.c_double * 3) * 3)]
 
 
 class TickParams(C.Structure):
@@ -102,6 +111,10 @@ def lib() -> C.CDLL:
         L.wcqp_ik_solve_host.argtypes = ik_args
         L.wcqp_hull_from_feet_device.argtypes = [C.c_int32] + [C.c_void_p] * 8
         L.wcqp_hull_from_feet_host.argtypes = [C.c_int32] + [C.c_void_p] * 7
+        L.wcqp_kin_create.argtypes = [C.POINTER(KinParams), C.POINTER(C.c_void_p)]
+        L.wcqp_kin_destroy.argtypes = [C.c_void_p]
+        L.wcqp_kin_jacobians_device.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
+        L.wcqp_kin_jacobians_host.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
         L.wcqp_tick_create.argtypes = [C.POINTER(TickParams), C.POINTER(C.c_void_p)]
         L.wcqp_tick_destroy.argtypes = [C.c_void_p]
         L.wcqp_tick_upload.argtypes = [C.c_void_p, C.POINTER(TickInputs)]
@@ -253,6 +266,58 @@ def hull_from_feet_host(foot_rect, left_T, right_T, contact):
     check(lib().wcqp_hull_from_feet_host(B, _p(foot_rect), _p(left_T), _p(right_T), _p(contact), _p(A), _p(b), _p(nc)),
           "wcqp_hull_from_feet_host")
     return A, b, nc
+
+
+class KinModel:
+    """Handle over wcqp_kin_* - batched forward kinematics + MIXED free-floating Jacobians.
+    `model` is a table as returned by `synth.icub_like_model()`."""
+
+    def __init__(self, model: dict):
+        n = int(model["dof"])
+        p = KinParams()
+        p.dof = n
+        for j in range(n):
+            p.parent[j] = int(model["parent"][j])
+            for k in range(9):
+                p.R0[j][k] = float(np.asarray(model["R0"][j]).reshape(9)[k])
+            for k in range(3):
+                p.p0[j][k] = float(model["p0"][j][k]); p.axis[j][k] = float(model["axis"][j][k]); p.com[j][k] = float(model["com"][j][k])
+            p.mass[j] = float(model["mass"][j])
+        p.root_mass = float(model["root_mass"])
+        for k in range(3):
+            p.root_com[k] = float(model["root_com"][k])
+        for f in range(3):
+            p.frame_joint[f] = int(model["frame_joint"][f])
+            for k in range(9):
+                p.frame_R[f][k] = float(np.asarray(model["frame_R"][f]).reshape(9)[k])
+            for k in range(3):
+                p.frame_p[f][k] = float(model["frame_p"][f][k])
+        self.params, self.dof = p, n
+        self._h = C.c_void_p()
+        check(lib().wcqp_kin_create(C.byref(p), C.byref(self._h)), "wcqp_kin_create")
+
+    def close(self):
+        if self._h:
+            lib().wcqp_kin_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def jacobians_host(self, base, q, state=None):
+        base, q = _f64(base), _f64(q)
+        B, nc = q.shape[0], 6 + self.dof
+        JL = np.zeros((B, 6, nc)); JR = np.zeros((B, 6, nc)); JN = np.zeros((B, 3, nc)); JC = np.zeros((B, 3, nc))
+        st = None if state is None else _f64(state).copy()
+        check(lib().wcqp_kin_jacobians_host(self._h, B, _p(base), _p(q), _p(JL), _p(JR), _p(JN), _p(JC), _p(st)), "wcqp_kin_jacobians_host")
+        return dict(J_left=JL, J_right=JR, J_neck=JN, J_com=JC, state=st)
+
+    def jacobians_device(self, batch, base, q, J_left, J_right, J_neck, J_com, state=0, stream=0):
+        check(lib().wcqp_kin_jacobians_device(self._h, int(batch), base, q, J_left, J_right, J_neck, J_com, state or None, stream or None),
+              "wcqp_kin_jacobians_device")
 
 
 class TickPipeline:

@@ -317,3 +317,64 @@ def synth_tick_batch(count: int, n_ticks: int, seed: int = 2718, horizon: int = 
                 J_right=ik["J_right"], J_neck=ik["J_neck"], J_com=ik["J_com"], state0=ik["state"],
                 swing_twist=np.ascontiguousarray(swing), q0=ik["q"], dcm0=np.ascontiguousarray(dcm0),
                 com0=np.ascontiguousarray(dcm0.copy()), u_init=np.ascontiguousarray(zmp[:, 0].copy()))
+
+
+# ------------------------------------------------------------------------------------------------
+# kinematics.  The reference reads its robot model from an external URDF
+# (`model.urdf`, WM/src/WalkingModule.cpp:107) that is not part of the repository, so the tree below
+# is iCub-SHAPED, not iCub: same joint list and order (CFG/robotControl.ini:3-7), same chain
+# topology (torso 3 -> arms 4 + 4; legs 6 + 6 from the root link), plausible link lengths, masses
+# and axes.  A table derived from the real URDF has the same form and goes through the same ABI.
+JOINT_NAMES = ("torso_pitch", "torso_roll", "torso_yaw",
+               "l_shoulder_pitch", "l_shoulder_roll", "l_shoulder_yaw", "l_elbow",
+               "r_shoulder_pitch", "r_shoulder_roll", "r_shoulder_yaw", "r_elbow",
+               "l_hip_pitch", "l_hip_roll", "l_hip_yaw", "l_knee", "l_ankle_pitch", "l_ankle_roll",
+               "r_hip_pitch", "r_hip_roll", "r_hip_yaw", "r_knee", "r_ankle_pitch", "r_ankle_roll")
+
+
+def _rot_axis(axis, angle):
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+
+def icub_like_model() -> dict:
+    """Kinematic tree in the table form of `wcqp_kin_params`: joint j has parent joint `parent[j]` (-1 = root
+    link, always < j), a fixed transform (R0, p0) from the parent joint frame to its own frame at q = 0, a unit
+    axis in its own frame, and carries one link (mass, centre of mass in the joint frame).  Three frames are
+    attached: left sole, right sole, neck."""
+    X, Y, Z = (1.0, 0, 0), (0, 1.0, 0), (0, 0, 1.0)
+    parent = [-1, 0, 1, 2, 3, 4, 5, 2, 7, 8, 9, -1, 11, 12, 13, 14, 15, -1, 17, 18, 19, 20, 21]
+    axis = [Y, X, Z, Y, X, Z, Y, Y, X, Z, Y, Y, X, Z, Y, Y, X, Y, X, Z, Y, Y, X]
+    p0 = [(0, 0, 0.12), (0, 0, 0.03), (0, 0, 0.03),
+          (0.0, 0.11, 0.14), (0, 0.02, 0), (0, 0, -0.07), (0.015, 0, -0.08),
+          (0.0, -0.11, 0.14), (0, -0.02, 0), (0, 0, -0.07), (0.015, 0, -0.08),
+          (0, 0.068, -0.04), (0, 0, -0.01), (0, 0, -0.03), (0, 0, -0.22), (0, 0, -0.21), (0, 0, -0.02),
+          (0, -0.068, -0.04), (0, 0, -0.01), (0, 0, -0.03), (0, 0, -0.22), (0, 0, -0.21), (0, 0, -0.02)]
+    R0 = [np.eye(3) for _ in range(23)]
+    R0[3] = _rot_axis(X, np.deg2rad(15.0)); R0[7] = _rot_axis(X, np.deg2rad(-15.0))      # shoulders tilted outwards
+    R0[13] = _rot_axis(Z, np.deg2rad(2.0)); R0[19] = _rot_axis(Z, np.deg2rad(-2.0))
+    mass = [1.2, 0.9, 4.5, 1.1, 0.4, 0.9, 0.8, 1.1, 0.4, 0.9, 0.8,
+            1.4, 0.6, 1.9, 1.3, 0.5, 0.7, 1.4, 0.6, 1.9, 1.3, 0.5, 0.7]
+    com = [(0, 0, 0.01), (0, 0, 0.01), (0.005, 0, 0.10), (0, 0, -0.02), (0, 0, 0), (0, 0, -0.04), (0.01, 0, -0.06),
+           (0, 0, -0.02), (0, 0, 0), (0, 0, -0.04), (0.01, 0, -0.06),
+           (0, 0, -0.01), (0, 0, 0), (0, 0, -0.10), (0, 0, -0.10), (0, 0, -0.01), (0.02, 0, -0.03),
+           (0, 0, -0.01), (0, 0, 0), (0, 0, -0.10), (0, 0, -0.10), (0, 0, -0.01), (0.02, 0, -0.03)]
+    return dict(dof=23, parent=np.array(parent, np.int32), axis=np.array(axis, float), p0=np.array(p0, float),
+                R0=np.stack(R0), mass=np.array(mass, float), com=np.array(com, float),
+                root_mass=5.8, root_com=np.array([-0.01, 0.0, 0.02]),
+                frame_joint=np.array([16, 22, 2], np.int32),          # left sole, right sole, neck
+                frame_p=np.array([(0.02, 0, -0.045), (0.02, 0, -0.045), (0, 0, 0.20)], float),
+                frame_R=np.stack([np.eye(3), np.eye(3), _rot_axis(Y, np.deg2rad(5.0))]))
+
+
+def synth_kin_batch(count: int, seed: int = 31415, first: int = 0) -> dict:
+    """Base poses ([B][12]: position, row-major rotation) and joint angles [B][23] around the posture the
+    reference regularises to (ICUB_JOINT_REG_DEG), shard-invariant like the other generators."""
+    rng = CounterRNG(seed, first, count)
+    q = np.deg2rad(ICUB_JOINT_REG_DEG)[None, :] + rng.normal(23, 0.25)
+    pos = rng.normal(3, 1.0) * np.array([0.05, 0.05, 0.02]) + np.array([0.0, 0.0, 0.55])
+    w = rng.normal(3, 0.15)
+    R = np.stack([_rot_axis(wi / (np.linalg.norm(wi) + 1e-300), np.linalg.norm(wi)) for wi in w])
+    base = np.concatenate([pos, R.reshape(count, 9)], axis=1)
+    return dict(q=np.ascontiguousarray(q), base=np.ascontiguousarray(base))
