@@ -315,7 +315,7 @@ def test_ik_16lane_kernel_on_ragged_batches(wca, batch):
 def test_ik_kernels_agree_under_tight_bounds(wca, vmax):
     """Many active bounds (6..10 per instance, working-set drops, infeasible instances): the three
     kernels walk the same dual active set, so status, active sets and solutions must coincide
-    (`tools/stress_ik.py` runs the same comparison on 200 k instances)."""
+    (`tools/stress_ik.py` runs the same comparison on 300 k instances)."""
     B = 4000
     b = wca.synth.synth_ik_batch(B, seed=303)
     args = (b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
