@@ -55,8 +55,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="tick workload: plain launches instead of hipGraph replay")
     ap.add_argument("--streams", type=int, choices=[0, 1, 2], default=0,
                     help="qp workload: 2 = the (independent) MPC and IK batches go to two HIP streams and may overlap; "
-                         "0 = auto: 2 up to 16384 robots per GPU (+18 %% at 4096: the IK kernel runs one wave per SIMD "
-                         "and the MPC kernel fits beside it), 1 above (at 65536 the overlap slows the IK kernel more than it saves)")
+                         "0 = auto: 2 up to 32768 robots per GPU (+18 %% at 4096, +18 %% at 8192, +9 %% at 16384, +2 %% at 32768: the MPC "
+                         "kernel fits beside the IK kernel), 1 above (at 65536 the overlap slows the IK kernel more than it saves)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     args = ap.parse_args()
@@ -115,7 +115,7 @@ def main():
     ik = wca.IkSolver(form=wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP, v_max=args.ik_vmax)
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
-    n_streams = args.streams if args.streams else (2 if B <= 16384 else 1)
+    n_streams = args.streams if args.streams else (2 if B <= 32768 else 1)
     two_streams = n_streams == 2 and not (args.exchange and world > 1)
     stream_mpc = torch.cuda.Stream(dev) if two_streams else stream
     sp_mpc = stream_mpc.cuda_stream
