@@ -312,7 +312,9 @@ def bench_kin(args, wca, torch, dist, dev, world, rank, B, first):
                      "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per * B},
     }
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
