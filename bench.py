@@ -154,6 +154,8 @@ def main():
             dist.gather(dq, gat_dq if rank == 0 else None, dst=0)
         exch = (exch_in, exch_out)
 
+    bracket_ik = [False]      # two streams with fewer than 2 sampled steps: fall back to bracketing the IK launch
+
     def step(ev=None):
         if exch:
             exch[0]()
@@ -161,7 +163,7 @@ def main():
         if ev is not None:
             ev[0].record(stream)
         launch_ik()
-        if ev is not None and not two_streams:
+        if ev is not None and (not two_streams or bracket_ik[0]):
             ev[1].record(stream)
         if exch:
             exch[1]()
@@ -181,6 +183,7 @@ def main():
     # average duration is the time between consecutive events / stride (inter-launch gap included).
     stride = max(1, int(os.environ.get("WCQP_BENCH_EVENT_STRIDE", str(max(1, min(8, args.steps // 8))))))
     events = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, stride)}
+    bracket_ik[0] = len(events) < 2
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events.get(k))
