@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WCQP_VERSION 100
+#define WCQP_VERSION 200
 
 /* return codes */
 #define WCQP_OK              0
@@ -51,6 +51,8 @@ extern "C" {
 #define WCQP_STATUS_OUTSIDE_HULL  3   /* MPC: margin(u0) < -convex_hull_tolerance
                                          (WM/src/WalkingDCMModelPredictiveController.cpp:513-517) */
 #define WCQP_STATUS_NUMERIC       4   /* non-positive pivot (KKT not regular)             */
+#define WCQP_STATUS_STRUCTURE     5   /* IK: handle created with WCQP_IK_JAC_MIXED, but this instance's Jacobians do
+                                         not have MIXED-representation base blocks          */
 
 #define WCQP_HULL_ROWS   8            /* hull rows are padded to 8 per instance           */
 #define WCQP_MAX_DOF     32
@@ -158,6 +160,18 @@ int wcqp_hull_from_feet_host(int32_t batch, const double* foot_rect,
 #define WCQP_IK_ALG_NULLSPACE_16L 4    /* null-space kernel on 16 lanes per instance, 4 instances per wave
                                           (csrc/ik3.hip): 1.6x the throughput of 3 on a full chip, ahead at every batch
                                           size (the default); needs use_com_as_constraint, else runs as 2       */
+#define WCQP_IK_ALG_BASE_ELIM 5        /* base unknowns eliminated in closed form through the left-foot rows, 23-variable
+                                          QP in range space (csrc/ik4.hip): what the default resolves to when the CoM is a
+                                          constraint, every joint weight is > 0 and the neck weight is positive definite;
+                                          otherwise runs as 4.  See `jacobian_structure`.                        */
+/* jacobian_structure: what the caller promises about the base blocks (columns 0..5) of the four Jacobians.
+ * The reference always passes iDynTree free-floating Jacobians in MIXED representation
+ * (WM/src/WalkingForwardKinematics.cpp:33, 436-454): J_left/J_right = [I B; 0 I | .], J_com = [I B | .],
+ * J_neck (angular rows) = [0 I | .].  Algorithm 5 relies on that pattern and CHECKS it per instance (exact 1.0 / 0.0). */
+#define WCQP_IK_JAC_AUTO    0    /* default: instances without the pattern are re-solved by the general kernel (one
+                                    more, nearly empty, launch per call)                                          */
+#define WCQP_IK_JAC_MIXED   1    /* instances without the pattern come back WCQP_STATUS_STRUCTURE (dq = 0); one launch */
+#define WCQP_IK_JAC_GENERAL 2    /* arbitrary Jacobians: the general kernel (algorithm 4) only                     */
 #define WCQP_IK_FORM_OSQP    1   /* joint-limit rows are zero rows (never bind), extra
                                     k_attFoot on the neck gradient term, zero-twist rule
                                                                */
@@ -177,9 +191,11 @@ typedef struct wcqp_ik_params {
     double  k_pos_com, k_pos_foot, k_att_foot, k_neck;
     double  rho;                         /* weight of the A'A term that regularises H; 0 -> 1  */
     double  tol;                         /* bound-violation tolerance; 0 -> 1e-12              */
-    int32_t algorithm;                   /* WCQP_IK_ALG_*: 0 -> default (4; 2 for CoM-as-cost), 1 = sweep on H + rho A'A (csrc/ik.hip),
+    int32_t algorithm;                   /* WCQP_IK_ALG_*: 0 -> default (5; 2 for CoM-as-cost), 1 = sweep on H + rho A'A (csrc/ik.hip),
                                             2 / 3 = null-space (csrc/ik2.hip) without / with MFMA, 4 = null-space on
-                                            16 lanes per instance (csrc/ik3.hip); same optimum */
+                                            16 lanes per instance (csrc/ik3.hip), 5 = base elimination + range space
+                                            (csrc/ik4.hip); same optimum */
+    int32_t jacobian_structure;          /* WCQP_IK_JAC_* (algorithms 0 / 5 only)               */
 } wcqp_ik_params;
 
 typedef struct wcqp_ik_s* wcqp_ik_t;

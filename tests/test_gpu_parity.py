@@ -18,6 +18,11 @@ pytestmark = pytest.mark.gpu
 
 SOL_TOL = 1e-9
 MARGIN = 1e-7
+# IK kernels: 0 = default dispatch (base elimination + range space, csrc/ik4.hip, general kernel behind it),
+# 5 = the same asked for explicitly, 4 = general 16-lane null-space kernel (csrc/ik3.hip: the fall-back),
+# 3 = 32-lane null-space kernel with the MFMA Gram tile (csrc/ik2.hip: kept as the independent cross-check)
+ALGS = [0, 5, 4, 3]
+ALG_IDS = ["default", "base_elim", "nullspace_16l", "nullspace_mfma"]
 
 
 def _load(golden_dir, name):
@@ -181,7 +186,7 @@ def _ik_solver(wca, form, vmax, algorithm=0):
                         algorithm=algorithm)
 
 
-@pytest.mark.parametrize("algorithm", [4, 3, 2, 1], ids=["nullspace_16l", "nullspace_mfma", "nullspace", "sweep"])
+@pytest.mark.parametrize("algorithm", ALGS, ids=ALG_IDS)
 @pytest.mark.parametrize("name", ["ik_qpoases_v050_b1024.npz", "ik_qpoases_v030_b512.npz", "ik_osqp_b512.npz"])
 def test_ik_matches_golden(wca, golden_dir, name, algorithm):
     g = _load(golden_dir, name)
@@ -200,7 +205,7 @@ def test_ik_matches_golden(wca, golden_dir, name, algorithm):
     assert np.array_equal(out["active_upper"][cc], g["active_upper"][cc])
 
 
-@pytest.mark.parametrize("algorithm", [4, 3, 2, 1], ids=["nullspace_16l", "nullspace_mfma", "nullspace", "sweep"])
+@pytest.mark.parametrize("algorithm", ALGS, ids=ALG_IDS)
 @pytest.mark.parametrize("form,vmax", [("qpoases", 0.4), ("qpoases", 0.22), ("osqp", 0.3)])
 def test_ik_against_oracle_live(wca, qs, form, vmax, algorithm):
     B = 160
@@ -237,7 +242,7 @@ def test_ik_osqp_form_quirks(wca, qs):
     assert np.abs(a["dq"] - q["dq"]).max() > 1e-3
 
 
-@pytest.mark.parametrize("algorithm", [4, 3, 2, 1], ids=["nullspace_16l", "nullspace_mfma", "nullspace", "sweep"])
+@pytest.mark.parametrize("algorithm", ALGS, ids=ALG_IDS)
 def test_ik_com_as_cost_variant(wca, qs, algorithm):
     """useCoMAsConstraint = 0: 12 equality rows, CoM task moves into the cost."""
     B = 48
@@ -259,12 +264,61 @@ def test_ik_stance_foot_touches_only_the_base(wca, qs):
     b = wca.synth.synth_ik_batch(B, seed=23)
     JL = b["J_left"].copy(); JL[:, :, 6:] = 0.0
     p = qs.IKParams(v_max=5.0 * np.ones(23))
-    for alg in (4, 3, 2, 1):
+    for alg in (0, 4, 3):
         out = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=5.0, algorithm=alg).solve_host(JL, b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
         for i in range(B):
             x = qs.ik_inputs_from_batch(dict(b, J_left=JL), i)
             r = qs.ik_exact(p, x, "qpoases")
             assert out["status"][i] == 0 and np.abs(out["dq"][i] - r["dq"]).max() <= SOL_TOL
+
+
+def _to_body_fixed(b, rows, rng):
+    """Re-expresses the base velocity of the listed instances in a rotated base frame: nu_base = blkdiag(R, R) nu',
+    i.e. every Jacobian's base block is right-multiplied by blkdiag(R, R).  Same joint-space problem, but the base
+    blocks are no longer [I B; 0 I]."""
+    out = {k: v.copy() for k, v in b.items()}
+    for i in rows:
+        w = rng.normal(0, 0.7, 3)
+        th = np.linalg.norm(w); k = w / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+        X = np.zeros((6, 6)); X[:3, :3] = R; X[3:, 3:] = R
+        for name in ("J_left", "J_right", "J_neck", "J_com"):
+            out[name][i][:, :6] = out[name][i][:, :6] @ X
+    return out
+
+
+def test_ik_jacobian_structure_fallback(wca, qs):
+    """The default kernel relies on MIXED-representation base blocks and checks them per instance.  Instances without
+    the pattern must (a) be re-solved by the general kernel under WCQP_IK_JAC_AUTO, with the oracle's optimum,
+    (b) come back WCQP_STATUS_STRUCTURE under WCQP_IK_JAC_MIXED while their neighbours are solved,
+    (c) agree with the all-general path (WCQP_IK_JAC_GENERAL) everywhere."""
+    B, vmax = 203, 0.4
+    rng = np.random.default_rng(5)
+    b = wca.synth.synth_ik_batch(B, seed=61)
+    odd = sorted(rng.choice(B, 37, replace=False).tolist() + [B - 1])
+    bb = _to_body_fixed(b, odd, rng)
+    args = (bb["J_left"], bb["J_right"], bb["J_neck"], bb["J_com"], bb["q"], bb["state"])
+    p = qs.IKParams(v_max=vmax * np.ones(23))
+    auto = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, jacobian_structure=wca.IK_JAC_AUTO).solve_host(*args)
+    gen = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, jacobian_structure=wca.IK_JAC_GENERAL).solve_host(*args)
+    mix = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, jacobian_structure=wca.IK_JAC_MIXED).solve_host(*args)
+    is_odd = np.zeros(B, bool); is_odd[odd] = True
+    assert (mix["status"][is_odd] == wca.STATUS_STRUCTURE).all() and (mix["dq"][is_odd] == 0).all()
+    assert (mix["status"][~is_odd] != wca.STATUS_STRUCTURE).all()
+    assert np.array_equal(mix["dq"][~is_odd], auto["dq"][~is_odd])
+    assert (auto["status"] == gen["status"]).all() and (auto["status"] != wca.STATUS_STRUCTURE).all()
+    assert np.array_equal(auto["dq"][is_odd], gen["dq"][is_odd])              # same kernel solved them
+    ok = gen["status"] == 0
+    assert np.abs(auto["dq"][ok] - gen["dq"][ok]).max() <= 1e-10
+    assert (auto["active_lower"][ok] == gen["active_lower"][ok]).all() and (auto["active_upper"][ok] == gen["active_upper"][ok]).all()
+    for i in odd[:12]:
+        r = qs.ik_exact(p, qs.ik_inputs_from_batch(bb, i), "qpoases")
+        assert auto["status"][i] == 0 and np.abs(auto["dq"][i] - r["dq"]).max() <= SOL_TOL
+    # a rotated base frame changes the base velocity's coordinates, not the joint velocities
+    plain = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    both = ok & (plain["status"] == 0)
+    assert np.abs(plain["dq"][both] - auto["dq"][both]).max() <= 1e-9
 
 
 def test_ik_properties_at_full_size(wca):
@@ -302,12 +356,13 @@ def test_ik_16lane_kernel_on_ragged_batches(wca, batch):
     b = wca.synth.synth_ik_batch(batch, seed=77)
     args = (b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
     ref = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, algorithm=3).solve_host(*args)
-    out = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, algorithm=4).solve_host(*args)
-    assert (out["status"] == ref["status"]).all()
-    ok = ref["status"] == 0
-    assert np.abs(out["dq"][ok] - ref["dq"][ok]).max(initial=0.0) <= 1e-10
-    assert (out["active_lower"][ok] == ref["active_lower"][ok]).all() and (out["active_upper"][ok] == ref["active_upper"][ok]).all()
-    assert np.abs(out["foot_err"][ok] - ref["foot_err"][ok]).max(initial=0.0) <= 1e-10
+    for alg in (0, 4):
+        out = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, algorithm=alg).solve_host(*args)
+        assert (out["status"] == ref["status"]).all()
+        ok = ref["status"] == 0
+        assert np.abs(out["dq"][ok] - ref["dq"][ok]).max(initial=0.0) <= 1e-10
+        assert (out["active_lower"][ok] == ref["active_lower"][ok]).all() and (out["active_upper"][ok] == ref["active_upper"][ok]).all()
+        assert np.abs(out["foot_err"][ok] - ref["foot_err"][ok]).max(initial=0.0) <= 1e-10
 
 
 @pytest.mark.gpu
@@ -319,10 +374,10 @@ def test_ik_kernels_agree_under_tight_bounds(wca, vmax):
     B = 4000
     b = wca.synth.synth_ik_batch(B, seed=303)
     args = (b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
-    outs = {a: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=a).solve_host(*args) for a in (4, 3, 1)}
+    outs = {a: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=a).solve_host(*args) for a in (0, 4, 3)}
     ref = outs[3]
     assert 0.3 * B < (ref["status"] == 0).sum() < B          # a real mix of solved and infeasible instances
-    for a in (4, 1):
+    for a in (0, 4):
         o = outs[a]
         assert (o["status"] == ref["status"]).all()
         ok = ref["status"] == 0

@@ -18,9 +18,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WCQP_LIB_PATH") or os.path.join(_HERE, "libwcqp.so")   # override: diagnostic builds only
 
 WCQP_OK = 0
-STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_OUTSIDE_HULL, STATUS_NUMERIC = range(5)
+STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_OUTSIDE_HULL, STATUS_NUMERIC, STATUS_STRUCTURE = range(6)
 IK_FORM_QPOASES, IK_FORM_OSQP = 0, 1
-IK_ALG_DEFAULT, IK_ALG_SWEEP, IK_ALG_NULLSPACE, IK_ALG_NULLSPACE_MFMA, IK_ALG_NULLSPACE_16L = 0, 1, 2, 3, 4
+IK_ALG_DEFAULT, IK_ALG_SWEEP, IK_ALG_NULLSPACE, IK_ALG_NULLSPACE_MFMA, IK_ALG_NULLSPACE_16L, IK_ALG_BASE_ELIM = 0, 1, 2, 3, 4, 5
+IK_JAC_AUTO, IK_JAC_MIXED, IK_JAC_GENERAL = 0, 1, 2
 HULL_ROWS = 8
 MAX_DOF = 32
 IK_STATE_LEN = 87
@@ -56,7 +57,8 @@ class IkParams(C.Structure):
                 ("v_min", C.c_double * MAX_DOF), ("v_max", C.c_double * MAX_DOF),
                 ("k_pos_com", C.c_double), ("k_pos_foot", C.c_double),
                 ("k_att_foot", C.c_double), ("k_neck", C.c_double),
-                ("rho", C.c_double), ("tol", C.c_double), ("algorithm", C.c_int32)]
+                ("rho", C.c_double), ("tol", C.c_double), ("algorithm", C.c_int32),
+                ("jacobian_structure", C.c_int32)]
 
 
 class KinParams(C.Structure):
@@ -201,7 +203,7 @@ class IkSolver:
                  com_weight=None, neck_weight=None, joint_reg_weights=None, joint_reg_gains=None,
                  joint_reg_rad=None, v_min=None, v_max=None,
                  k_pos_com=1.0, k_pos_foot=4.0, k_att_foot=2.0, k_neck=1.0,
-                 rho=0.0, tol=0.0, max_iter=0, algorithm=0):
+                 rho=0.0, tol=0.0, max_iter=0, algorithm=0, jacobian_structure=0):
         from .synth import ICUB_JOINT_REG_DEG
         com_weight = 100.0 * np.eye(3) if com_weight is None else np.asarray(com_weight, float)
         neck_weight = 5.0 * np.eye(3) if neck_weight is None else np.asarray(neck_weight, float)
@@ -220,7 +222,8 @@ class IkSolver:
         self.params = IkParams(dof, int(bool(use_com_as_constraint)), int(form), int(max_iter),
                                (C.c_double * 9)(*com_weight.reshape(-1)), (C.c_double * 9)(*neck_weight.reshape(-1)),
                                pad(joint_reg_weights), pad(joint_reg_gains), pad(joint_reg_rad),
-                               pad(v_min), pad(v_max), k_pos_com, k_pos_foot, k_att_foot, k_neck, rho, tol, int(algorithm))
+                               pad(v_min), pad(v_max), k_pos_com, k_pos_foot, k_att_foot, k_neck, rho, tol, int(algorithm),
+                               int(jacobian_structure))
         self.dof = dof
         self._h = C.c_void_p()
         check(lib().wcqp_ik_create(C.byref(self.params), C.byref(self._h)), "wcqp_ik_create")

@@ -432,6 +432,7 @@ int ensure_device(wcqp_ik_s* h) {
 namespace wcqp {
 int ik_prepare(wcqp_ik_t h) { return h ? ensure_device(h) : WCQP_E_INVALID; }
 const void* ik_device_params(wcqp_ik_t h) { return h ? h->d_prm : nullptr; }
+bool ik_fast_ok(wcqp_ik_t h) { return h && h->hp.fast_ok != 0; }
 }  // namespace wcqp
 
 extern "C" {
@@ -440,7 +441,8 @@ int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out) {
     if (!params || !out) return WCQP_E_INVALID;
     if (params->dof != kDof) return WCQP_E_UNSUPPORTED;      // kernels are unrolled for iCub's 23 DoF
     if (params->form != WCQP_IK_FORM_QPOASES && params->form != WCQP_IK_FORM_OSQP) return WCQP_E_INVALID;
-    if (params->algorithm < 0 || params->algorithm > WCQP_IK_ALG_NULLSPACE_16L) return WCQP_E_INVALID;
+    if (params->algorithm < 0 || params->algorithm > WCQP_IK_ALG_BASE_ELIM) return WCQP_E_INVALID;
+    if (params->jacobian_structure < WCQP_IK_JAC_AUTO || params->jacobian_structure > WCQP_IK_JAC_GENERAL) return WCQP_E_INVALID;
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < r; ++c)          // the kernels use W J and J'W interchangeably: symmetric weights only
             if (params->neck_weight[3 * r + c] != params->neck_weight[3 * c + r] ||
@@ -472,6 +474,35 @@ int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out) {
     d.tol = params->tol > 0 ? params->tol : 1e-12;
     d.form = params->form;
     d.max_iter = params->max_iter > 0 ? params->max_iter : 100;   // nWSR = 100, qp.cpp:312
+    // base-eliminated kernel (ik4.hip): column scaling Lam^-1/2 and the factor W_neck = L L'
+    d.fast_ok = params->use_com_as_constraint ? 1 : 0;
+    for (int c = 0; c < 32; ++c) { d.sd[c] = 1.0; d.isd[c] = 1.0; }
+    for (int j = 0; j < kDof; ++j) {
+        const double w = params->joint_reg_weights[j];
+        if (!(w > 0.0) || !std::isfinite(w)) { d.fast_ok = 0; continue; }
+        d.sd[j] = std::sqrt(1.0 / w); d.isd[j] = std::sqrt(w);
+    }
+    {
+        // Cholesky W = L L' (lower), stored as L' row-major; a neck weight that is not positive definite keeps the
+        // general kernels
+        const double* W = params->neck_weight;
+        double L[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bool pd = true;
+        for (int c = 0; c < 3 && pd; ++c) {
+            double dd = W[3 * c + c];
+            for (int k = 0; k < c; ++k) dd -= L[3 * c + k] * L[3 * c + k];
+            if (!(dd > 0.0) || !std::isfinite(dd)) { pd = false; break; }
+            L[3 * c + c] = std::sqrt(dd);
+            for (int r = c + 1; r < 3; ++r) {
+                double v = W[3 * r + c];
+                for (int k = 0; k < c; ++k) v -= L[3 * r + k] * L[3 * c + k];
+                L[3 * r + c] = v / L[3 * c + c];
+            }
+        }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) d.Lt[3 * r + c] = pd ? L[3 * c + r] : 0.0;
+        if (!pd) d.fast_ok = 0;
+    }
     *out = h;
     return WCQP_OK;
 }
@@ -494,9 +525,17 @@ int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
     if (batch == 0) return WCQP_OK;
     const int rc = ensure_device(h);
     if (rc != WCQP_OK) return rc;
-    // default: the 16-lanes-per-instance kernel (fastest at every batch size measured, 64 .. 65536:
-    // profiles/r01_ik_batch_sweep.json); it needs the CoM-as-constraint form (14 free variables + rhs <= 16 lanes)
-    const bool use16 = h->p.algorithm == WCQP_IK_ALG_NULLSPACE_16L || h->p.algorithm == WCQP_IK_ALG_DEFAULT;
+    // default: base elimination + range space (ik4.hip) for MIXED-representation Jacobians, with the general 16-lane
+    // kernel behind it for instances (or handles) that do not qualify
+    const bool want4 = h->p.algorithm == WCQP_IK_ALG_BASE_ELIM || h->p.algorithm == WCQP_IK_ALG_DEFAULT;
+    if (want4 && h->hp.fast_ok && h->p.jacobian_structure != WCQP_IK_JAC_GENERAL) {
+        const int rc4 = wcqp_ik::ik4_launch(h->d_prm, batch, J_left, J_right, J_neck, J_com, q, state, dq, status,
+                                            active_lower, active_upper, foot_err, iters, (hipStream_t)stream);
+        if (rc4 != WCQP_OK || h->p.jacobian_structure == WCQP_IK_JAC_MIXED) return rc4;
+        return wcqp_ik::ik3_launch_list(h->d_prm, batch, J_left, J_right, J_neck, J_com, q, state, dq, status,
+                                        active_lower, active_upper, foot_err, iters, (hipStream_t)stream);
+    }
+    const bool use16 = want4 || h->p.algorithm == WCQP_IK_ALG_NULLSPACE_16L;
     if (use16 && h->p.use_com_as_constraint)
         return wcqp_ik::ik3_launch(h->d_prm, batch, J_left, J_right, J_neck, J_com, q, state, dq, status,
                                    active_lower, active_upper, foot_err, iters, (hipStream_t)stream);

@@ -74,54 +74,49 @@ static_assert(PER_INST * 8 * 4 * 8 <= 160 * 1024, "8 blocks per CU");
 #define WCQP_STAMP(k) do { } while (0)
 #endif
 
-// all-reduce over the 16 lanes of a DPP row
-__device__ __forceinline__ unsigned row_max_u32(unsigned key) {
-    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));
-    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));
-    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x141, 0xf, 0xf, false));
-    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x140, 0xf, 0xf, false));
-    return key;
-}
-__device__ __forceinline__ double row_min(double v) {
-    v = fmin(v, dpp_move<0xB1>(v));
-    v = fmin(v, dpp_move<0x4E>(v));
-    v = fmin(v, dpp_move<0x141>(v));
-    v = fmin(v, dpp_move<0x140>(v));
-    return v;
-}
-__device__ __forceinline__ double row_max(double v) {
-    v = fmax(v, dpp_move<0xB1>(v));
-    v = fmax(v, dpp_move<0x4E>(v));
-    v = fmax(v, dpp_move<0x141>(v));
-    v = fmax(v, dpp_move<0x140>(v));
-    return v;
-}
-__device__ __forceinline__ unsigned mag_key(double v) { return __float_as_uint((float)fabs(v)) & ~31u; }
-
 // TICK: the receding-horizon pipeline's glue (ZMP-CoM law, plant; tick_device.h) runs in the prologue
 // and its post step (joint integration, next contact pair, tick counter) in the epilogue, so that a
 // tick is two launches (MPC, this) instead of four.
 #ifndef WCQP_IK3_WAVES
 #define WCQP_IK3_WAVES 2
 #endif
-template <bool TICK>
+// LIST: solves only the instances whose status reads WCQP_STATUS_STRUCTURE (what ik4.hip leaves behind for Jacobians
+// whose base blocks are not in MIXED form): a workgroup scans 64 status words, compacts the flagged ones into LDS and
+// loops over them four at a time; without any, the launch is batch / 64 workgroups that load one word and exit.
+template <bool TICK, bool LIST>
 __global__ __launch_bounds__(64, WCQP_IK3_WAVES)
 void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
                 const double* __restrict__ JN, const double* __restrict__ JC,
-                const double* __restrict__ qpos, const double* __restrict__ state,
+                const double* qpos, const double* __restrict__ state,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
-                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
+                double* __restrict__ ferr_out, int* __restrict__ iters_out,
+                wcqp_tick::TickDev td)
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
+    __shared__ int s_list[64];
 
+    int n_work = batch;
+    long w0 = (long)blockIdx.x * 4, wstep = (long)gridDim.x * 4;
+    if constexpr (LIST) {
+        const long cand = (long)blockIdx.x * 64 + threadIdx.x;
+        const bool flag = cand < batch && status_out[cand] == WCQP_STATUS_STRUCTURE;
+        const unsigned long long m = __ballot(flag);
+        n_work = __popcll(m);
+        if (n_work == 0) return;
+        if (flag) s_list[__popcll(m & ((1ull << threadIdx.x) - 1ull))] = (int)cand;
+        wcqp::wave_lds_fence();
+        w0 = 0; wstep = 4;
+    }
+  for (long wbase = w0; wbase < n_work; wbase += wstep) {
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int j = lane & 15;                        // owns columns j (slot 0) and j + 16 (slot 1)
-    const long inst_raw = (long)blockIdx.x * 4 + grp;
-    const bool live = inst_raw < batch;
-    const long inst = live ? inst_raw : (long)batch - 1;
+    const long inst_raw = wbase + grp;
+    const bool live = inst_raw < n_work;
+    const long inst_idx = live ? inst_raw : (long)n_work - 1;
+    const long inst = LIST ? (long)s_list[inst_idx] : inst_idx;
     double* S = smem[grp];
     double* F = S + OFF_F;
     double* st = S + OFF_ST;
@@ -930,6 +925,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     WCQP_STAMP(9);
     return;
 #endif
+    static_assert(!(TICK && LIST), "the tick pipeline does not use the list mode");
     if constexpr (TICK) {
         const bool ik_ok = st_code == WCQP_STATUS_SOLVED;
         if (live) {
@@ -971,6 +967,9 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             ferr_out[inst * 12 + j] = acc;
         }
     }
+    if constexpr (!LIST) break;        // one pass: keeps the plain kernel's code what it was before the list mode
+    wcqp::wave_lds_fence();
+  }
 }
 
 }  // namespace
@@ -982,7 +981,18 @@ int ik3_launch(const IkDeviceParams* d_prm, int batch,
                const double* q, const double* state, double* dq, int* status,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
     const unsigned grid = (unsigned)((batch + 3) / 4);
-    hipLaunchKernelGGL(ik3_kernel<false>, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+    hipLaunchKernelGGL((ik3_kernel<false, false>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+                       dq, status, alo, aup, ferr, iters, wcqp_tick::TickDev{});
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+int ik3_launch_list(const IkDeviceParams* d_prm, int batch,
+                    const double* JL, const double* JR, const double* JN, const double* JC,
+                    const double* q, const double* state, double* dq, int* status,
+                    unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
+    const unsigned grid = (unsigned)((batch + 63) / 64);
+    hipLaunchKernelGGL((ik3_kernel<false, true>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
                        dq, status, alo, aup, ferr, iters, wcqp_tick::TickDev{});
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
@@ -993,7 +1003,7 @@ int ik3_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
                     unsigned* alo, unsigned* aup, hipStream_t stream) {
     if (!d_prm) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((td.batch + 3) / 4);
-    hipLaunchKernelGGL(ik3_kernel<true>, dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
+    hipLaunchKernelGGL((ik3_kernel<true, false>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
                        JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;

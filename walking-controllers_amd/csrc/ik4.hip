@@ -1,0 +1,832 @@
+// Jacobian QP-IK, fourth kernel: the six base unknowns eliminated in CLOSED FORM through the left-foot rows, the
+// remaining 23-variable QP solved in range space.  16 lanes per instance (one DPP row), 4 instances per wave64.
+//
+// Same QP, inputs, outputs and reference citations as ik.hip / ik2.hip / ik3.hip
+// (WM/src/WalkingQPInverseKinematics_qpOASES.cpp:135-401, _osqp.cpp:135-454).  What is different:
+//
+// The Jacobians the reference hands to the IK are iDynTree free-floating frame Jacobians in MIXED representation
+// (WM/src/WalkingForwardKinematics.cpp:33, 436-454), whose base blocks are
+//     J_left = [I B_L; 0 I | J_Lq]   J_right = [I B_R; 0 I | J_Rq]   J_com = [I B_C | J_Cq]   J_neck(angular) = [0 I | J_Nq]
+// (B = -S(p_frame - p_base)).  The six left-foot rows then give the base velocity in closed form,
+//     v_base = X_L^-1 (b_L - J_Lq x),   X_L^-1 = [I -B_L; 0 I],   x = joint velocities,
+// and what is left is
+//     min 1/2 x' Lam x + gq' x + 1/2 |Nt x - t|^2     s.t.   A x = b',   lo <= x <= hi
+//     A  = [J_Rq - X_R X_L^-1 J_Lq ; J_Cq - X_C X_L^-1 J_Lq]   (9 x 23)      row operations, local to a column
+//     Nt = L' (J_Nq - J_Lq,ang),  W_neck = L L',   Lam = diag(joint weights) > 0
+// With Lam > 0 the Hessian needs no null-space basis: in the scaled variable x~ = Lam^1/2 x and C = [Nt; A] Lam^-1/2
+// (12 x 23)
+//     M y = -(C g~ + [t; b']),   M = C C' + diag(I3, 0)   (12 x 12, SPD),      x~ = -(g~ + C' y)
+// i.e. ONE 12-pivot sweep without pivot search replaces the 15 searched pivots of the column-pivoted elimination
+// and the 14-pivot sweep of the reduced Hessian in ik3.hip; M is one fp64 MFMA tile per instance with the SAME
+// register as A and B operand.  The projected inverse Hessian P = I - C' M^-1 C feeds the same Goldfarb-Idnani
+// dual active set as the other kernels (first bound straight-line, up to 4 bounds replicated in registers, bigger
+// working sets slot-per-lane), so active sets stay bit-identical.
+//
+// Every instance checks its own base blocks for the pattern (exact 1.0 / 0.0 entries); one that does not have it
+// comes back WCQP_STATUS_STRUCTURE, and the dispatcher (ik.hip) runs the general kernel (ik3.hip, list mode) over the
+// flagged instances unless the handle was created for MIXED Jacobians only (include/wcqp.h: jacobian_structure).
+//
+// Lane j of an instance's 16 owns joint column j (slot 0) and, in slot 1: joint column 16 + j (j < 7), the
+// right-hand-side column [b_L; b_R; b_C; e_neck] (j = 7), base column j - 8 (j = 8 .. 13: pattern check and B blocks).
+// LDS 408 doubles per instance (13 KB per block: 12 blocks per CU = 3 waves per SIMD).
+// Template parameter TICK: the tick pipeline's glue / post steps fused in (tick_device.h).
+#include <cmath>
+#include <limits>
+#include "ik_common.h"
+#include "tick_device.h"
+
+namespace {
+
+using namespace wcqp_ik;
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int NR = 12;                // rows of C = [Nt (3); A_right (6); A_com (3)]
+constexpr int NROWS_IN = 18;          // J_left 6, J_right 6, J_com 3, J_neck 3
+constexpr int KMAX = kDof - 9;        // 14: largest working set (n - m_eq)
+constexpr int LDR = KMAX | 1;         // 15
+constexpr int LDC = 14;               // leading dimension of C^T (k-major) and of the Gram tile: b128 row accesses of 16
+                                      // lanes land on 16 distinct groups of 4 banks (28 j mod 64)
+
+// ---- LDS layout per instance (doubles) ---------------------------------------------------------
+// region A, three lives:
+//   set-up
+constexpr int OFF_ST = 0;             // [112] state + q
+constexpr int OFF_BV = 112;           // [18]  task rhs b (15) and neck target e (3)
+constexpr int OFF_DB = 130;           // [18]  B_R - B_L, B_C - B_L (row-major 3x3 each)
+//   Gram
+constexpr int OFF_CT = 0;             // [24][LDC] (+2): C^T k-major, row 12 = g~, row 13 = 0; k = 23: zero column
+constexpr int OFF_TILE = 0;           // [16][LDC] Gram tile
+//   active set
+constexpr int OFF_CPV = 0;            // [16] column p of C
+constexpr int OFF_YPV = 16;           // [16] M^-1 C v
+constexpr int OFF_TPB = 32;           // [32] signed column tau_p by variable
+constexpr int OFF_RV = 64;            // [16] dual step per slot
+constexpr int OFF_CV = 80;            // [16]
+constexpr int OFF_WI = 96;            // [16] ints: variable of slot a
+constexpr int OFF_RINV = 104;         // [KMAX][LDR]
+constexpr int OFF_PB = 0;             // [12][18] foot-error partial products (epilogue)
+constexpr int A_SIZE = 340;
+// region B
+constexpr int OFF_COL = A_SIZE;       // [2][16] sweep columns
+constexpr int OFF_YV = A_SIZE + 32;   // [16] y
+constexpr int OFF_DV = A_SIZE + 48;   // [16] d = [t; b'] by row
+constexpr int PER_INST = 408;         // = 24 mod 32: the four instances of a wave sit 16 banks apart
+static_assert(OFF_CT + 24 * LDC + 2 <= A_SIZE && OFF_RINV + KMAX * LDR <= A_SIZE && OFF_DB + 18 <= A_SIZE, "LDS overlays");
+static_assert(OFF_DV + 16 <= PER_INST && (PER_INST % 32 == 24 || PER_INST % 32 == 8), "instances 16 banks apart");
+static_assert(PER_INST * 8 * 4 * 12 <= 160 * 1024, "12 blocks per CU");
+
+#ifndef WCQP_IK4_WAVES
+#define WCQP_IK4_WAVES 2
+#endif
+
+__device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+
+template <bool TICK>
+__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
+void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
+                const double* __restrict__ JL, const double* __restrict__ JR,
+                const double* __restrict__ JN, const double* __restrict__ JC,
+                const double* qpos, const double* __restrict__ state,
+                double* __restrict__ dq_out, int* __restrict__ status_out,
+                unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
+                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
+
+    const int lane = threadIdx.x;
+    const int grp = lane >> 4;
+    const int j = lane & 15;
+    const long inst_raw = (long)blockIdx.x * 4 + grp;
+    const bool live = inst_raw < batch;
+    const long inst = live ? inst_raw : (long)batch - 1;
+    double* S = smem[grp];
+    double* st = S + OFF_ST;
+    const double inf = std::numeric_limits<double>::infinity();
+    const bool var1 = j < kDof - 16;                // slot 1 is joint 16 + j
+    const bool rhs1 = j == kDof - 16;               // slot 1 is the right-hand-side column
+    const bool base1 = j >= 8 && j < 14;            // slot 1 is base column j - 8
+    const int col1 = j + 16;
+
+    int tick_now = 0;
+    if constexpr (TICK) tick_now = *td.tick_latched;
+
+    // ---------------- phase 0: loads ------------------------------------------------------------
+    const int v0i = 6 + j, v1i = var1 ? 22 + j : 0;           // index into the per-variable constant tables
+    const double sd0 = prm->sd[j], sd1 = prm->sd[col1], isd0 = prm->isd[j], isd1 = prm->isd[col1];
+    const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
+    const double k_pos_foot = prm->k_pos_foot, k_att_foot = prm->k_att_foot, k_pos_com = prm->k_pos_com;
+    const double kap = prm->kappa * (-prm->k_neck);
+    const double kq0 = prm->kq[v0i], kq1 = prm->kq[v1i], qreg0 = prm->qreg[v0i], qreg1 = prm->qreg[v1i];
+    const int fast_ok = prm->fast_ok;
+    double a0[NROWS_IN], a1[NROWS_IN];     // columns of [J_left; J_right; J_com; J_neck]
+    double q0, q1;
+    {
+        // the state block first: vmcnt retires in order, and the rhs phase only needs the state, so the 36
+        // Jacobian loads stay in flight underneath it
+        const double* sp = state + inst * kStateLen;
+        double sreg[6];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
+        sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
+        q0 = qpos[inst * kDof + j];
+        q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
+        double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0;
+        if constexpr (TICK) {
+            if (live) {
+                const int i_ = (int)inst;
+                const int mst = td.mpc_status[i_];
+                const bool mpc_ok = mst == WCQP_STATUS_SOLVED || mst == WCQP_STATUS_OUTSIDE_HULL;
+                if (j < 2) wcqp_tick::tick_glue_axis(td, i_, tick_now, j, mpc_ok, g_com, g_pstar, g_vel);
+                if (j < 6) wcqp_tick::tick_glue_twist(td, i_, td.sel[i_], j, g_twl, g_twr);
+                if (j == 0 && !mpc_ok) td.mpc_fail[i_] += 1;
+            }
+        }
+        const int fc0 = 6 + j;
+        const int fc1 = var1 ? 22 + j : (base1 ? j - 8 : 0);
+        const double* jl = JL + inst * (6 * kNV);
+        const double* jr = JR + inst * (6 * kNV);
+        const double* jc = JC + inst * (3 * kNV);
+        const double* jn = JN + inst * (3 * kNV);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { a0[r] = jl[r * kNV + fc0]; a1[r] = jl[r * kNV + fc1]; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { a0[6 + r] = jr[r * kNV + fc0]; a1[6 + r] = jr[r * kNV + fc1]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { a0[12 + r] = jc[r * kNV + fc0]; a1[12 + r] = jc[r * kNV + fc1]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { a0[15 + r] = jn[r * kNV + fc0]; a1[15 + r] = jn[r * kNV + fc1]; }
+#pragma unroll
+        for (int m = 0; m < 5; ++m) st[m * 16 + j] = sreg[m];
+        if (80 + j < kStateLen) st[80 + j] = sreg[5];
+        if constexpr (TICK) {
+            wcqp::wave_lds_fence();
+            if (j < 2) { st[66 + j] = g_com; st[69 + j] = g_pstar; st[72 + j] = g_vel; }
+            if (j < 6) { st[75 + j] = g_twl; st[81 + j] = g_twr; }
+            if (j == 0) wcqp_tick::tick_glue_height(td, st);
+        }
+    }
+    wcqp::wave_lds_fence();
+
+    // ---------------- phase 1: task rhs b (lanes 0..14) and neck target e (lanes 13..15) ------------------
+    double b_mine = 0.0;
+    {
+        double* bv = S + OFF_BV;
+        if (j < 15) {
+            if (j < 12) {
+                const int foot = j / 6, k = j % 6;
+                const double* p  = st + (foot ? 12 : 0);
+                const double* R  = st + (foot ? 15 : 3);
+                const double* pd = st + (foot ? 36 : 24);
+                const double* Rd = st + (foot ? 39 : 27);
+                const double* tw = st + (foot ? 81 : 75);
+                const double corr = k < 3 ? k_pos_foot * (p[k] - pd[k]) : k_att_foot * rot_err(R, Rd, k - 3);
+                const bool skip = osqp_form && tw[0] == tw[1] && tw[0] == 0.0;        // osqp.cpp:286-306
+                b_mine = skip ? tw[k] : tw[k] - corr;
+            } else {
+                const int k = j - 12;
+                b_mine = st[72 + k] - k_pos_com * (st[66 + k] - st[69 + k]);
+            }
+            bv[j] = b_mine;
+        }
+        // neck target e = kappa (-k_neck) e_R(R_neck, R_neck,d)   (osqp.cpp:181-196, qp.cpp:161-178)
+        if (j >= 13) bv[15 + (j - 13)] = kap * rot_err(st + 48, st + 57, j - 13);
+    }
+    // gradient of the joint regularisation in the scaled variable: g~ = Lam^-1/2 (-w K (q_reg - q))
+    const double gt0 = -sd0 * kq0 * (qreg0 - q0);
+    const double gt1 = var1 ? -sd1 * kq1 * (qreg1 - q1) : 0.0;
+    wcqp::wave_lds_fence();
+    if (rhs1) {
+        const double* bv = S + OFF_BV;
+#pragma unroll
+        for (int r = 0; r < NROWS_IN; r += 2) { const double2 b2 = ld2(bv + r); a1[r] = b2.x; a1[r + 1] = b2.y; }
+    }
+
+    // ---------------- phase 2: base blocks: MIXED pattern check, B_R - B_L, B_C - B_L ---------------------
+    bool pat = true;
+    {
+        double* db = S + OFF_DB;
+        if (base1) {
+            const int cb = j - 8;
+            const bool lowc = cb < 3;
+            const int cm = lowc ? cb : cb - 3;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double id = (r == cm) ? 1.0 : 0.0;
+                const bool lo_ok = a1[r] == id && a1[3 + r] == 0.0 && a1[6 + r] == id && a1[9 + r] == 0.0 &&
+                                   a1[12 + r] == id && a1[15 + r] == 0.0;
+                const bool hi_ok = a1[3 + r] == id && a1[9 + r] == id && a1[15 + r] == id;
+                pat = pat && (lowc ? lo_ok : hi_ok);
+                if (!lowc) { db[r * 3 + cm] = a1[6 + r] - a1[r]; db[9 + r * 3 + cm] = a1[12 + r] - a1[r]; }
+            }
+        }
+    }
+    const bool use = fast_ok != 0 && ((__ballot(!pat) >> (16 * grp)) & 0xffffull) == 0ull;
+    wcqp::wave_lds_fence();
+
+    // ---------------- phase 3: row operations on the own columns -> C (scaled) -------------------------------
+    double c0[NR], c1[NR];
+    {
+        const double* db = S + OFF_DB;
+        double dBR[9], dBC[9];
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) { const double2 v = ld2(db + m); dBR[m] = v.x; dBR[m + 1] = v.y; }
+        { const double2 v = ld2(db + 8); dBR[8] = v.x; dBC[0] = v.y; }
+#pragma unroll
+        for (int m = 1; m < 9; m += 2) { const double2 v = ld2(db + 9 + m); dBC[m] = v.x; dBC[m + 1] = v.y; }
+        const double L00 = prm->Lt[0], L01 = prm->Lt[1], L02 = prm->Lt[2], L11 = prm->Lt[4], L12 = prm->Lt[5], L22 = prm->Lt[8];
+        auto xf = [&](const double (&a)[NROWS_IN], double sc, double (&c)[NR]) {
+            const double w0 = a[3], w1 = a[4], w2 = a[5];
+            const double n0 = a[15] - w0, n1 = a[16] - w1, n2 = a[17] - w2;
+            c[0] = sc * (L00 * n0 + L01 * n1 + L02 * n2);
+            c[1] = sc * (L11 * n1 + L12 * n2);
+            c[2] = sc * (L22 * n2);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                c[3 + r] = sc * (a[6 + r] - a[r] - (dBR[3 * r] * w0 + dBR[3 * r + 1] * w1 + dBR[3 * r + 2] * w2));
+                c[9 + r] = sc * (a[12 + r] - a[r] - (dBC[3 * r] * w0 + dBC[3 * r + 1] * w1 + dBC[3 * r + 2] * w2));
+            }
+            c[6] = sc * (a[9] - w0); c[7] = sc * (a[10] - w1); c[8] = sc * (a[11] - w2);
+        };
+        xf(a0, sd0, c0);
+        xf(a1, var1 ? sd1 : 1.0, c1);
+        if (!(var1 || rhs1)) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) c1[r] = 0.0;
+        }
+    }
+    wcqp::wave_lds_fence();           // ST / BV / DB are dead: C^T overlays them
+
+    // ---------------- phase 4: M = C C' + diag(I3, 0) and C g~ on one fp64 MFMA tile per instance ----------
+    double Hr[NR + 1];
+    {
+        double* ct = S + OFF_CT;
+        double* dv = S + OFF_DV;
+        {
+            double* c = ct + j * LDC;
+#pragma unroll
+            for (int r = 0; r < NR; r += 2) st2(c + r, c0[r], c0[r + 1]);
+            st2(c + NR, gt0, 0.0);
+        }
+        if (j < 8) {                                   // joints 16..22 and the zero column k = 23
+            double* c = ct + col1 * LDC;
+#pragma unroll
+            for (int r = 0; r < NR; r += 2) st2(c + r, rhs1 ? 0.0 : c1[r], rhs1 ? 0.0 : c1[r + 1]);
+            st2(c + NR, gt1, 0.0);
+        }
+        if (rhs1) {
+#pragma unroll
+            for (int r = 0; r < NR; r += 2) st2(dv + r, c1[r], c1[r + 1]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) c1[r] = 0.0;
+            ct[24 * LDC] = 0.0; ct[24 * LDC + 1] = 0.0;   // read by tile rows 14, 15 of the last k (ignored, but keep them finite)
+        }
+        wcqp::wave_lds_fence();
+        const int mk = lane & 15, mq = lane >> 4;
+        v4d acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double v = smem[g][OFF_CT + (4 * s + mq) * LDC + mk];      // A[i][k] and B[k][n] are the same entry
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc[g], 0, 0, 0);
+            }
+        }
+        wcqp::wave_lds_fence();
+        // C/D layout of the f64 tile: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) smem[g][OFF_TILE + (mq + 4 * reg) * LDC + mk] = acc[g][reg];
+        }
+        wcqp::wave_lds_fence();
+        // row j of [M | r] on lane j < 12, r' on lane 12 (the sweep treats it as one more row), zero rows above
+        const double* trow = S + OFF_TILE + j * LDC;
+        const bool rowok = j < NR, is12 = j == NR;
+        const double dj = dv[j < NR ? j : 0];
+#pragma unroll
+        for (int k = 0; k < NR; k += 2) {
+            const double2 h2 = ld2(trow + k);
+            const double2 d2 = ld2(dv + k);
+            Hr[k] = rowok ? h2.x + ((k == j && k < 3) ? 1.0 : 0.0) : (is12 ? -(h2.x + d2.x) : 0.0);
+            Hr[k + 1] = rowok ? h2.y + ((k + 1 == j && k + 1 < 3) ? 1.0 : 0.0) : (is12 ? -(h2.y + d2.y) : 0.0);
+        }
+        Hr[NR] = rowok ? -(trow[NR] + dj) : 0.0;
+    }
+    wcqp::wave_lds_fence();
+
+    // bounds and active-set settings: fetched here so that the latency hides under the sweep
+    const double tol = prm->tol;
+    const int max_iter = prm->max_iter;
+    double lo0 = prm->vlo[v0i] * isd0, hi0 = prm->vhi[v0i] * isd0, lo1 = prm->vlo[v1i] * isd1, hi1 = prm->vhi[v1i] * isd1;
+    // ---------------- phase 5: sweep over the 12 pivots (no search: M is SPD), y, x~ ----------------------
+    bool ok = true;
+    {
+        double* col = S + OFF_COL;
+        double pmin = 1.0;
+        col[j] = Hr[0];
+        wcqp::wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            double* cb = col + 16 * (k & 1);
+            double* nb = col + 16 * ((k + 1) & 1);
+            const double piv = cb[k];
+            pmin = (piv > 0.0) ? pmin : -1.0;
+            const double d = wcqp::fast_rcp(piv);
+            const double f0 = Hr[k] * d;
+            const double f = (j == k) ? (1.0 - d) : f0;
+            if (k + 1 < NR) {
+                Hr[k + 1] = fma(-f, cb[k + 1], Hr[k + 1]);
+                nb[j] = Hr[k + 1];                        // publish the next column early
+            }
+#pragma unroll
+            for (int q = 0; q <= NR; q += 2) {
+                const double2 c2 = ld2(cb + q);
+                if (q != k && !(q == k + 1 && k + 1 < NR)) Hr[q] = fma(-f, c2.x, Hr[q]);
+                if (q + 1 <= NR && q + 1 != k && !(q + 1 == k + 1 && k + 1 < NR)) Hr[q + 1] = fma(-f, c2.y, Hr[q + 1]);
+            }
+            Hr[k] = (j == k) ? -d : f0;
+            // hipcc otherwise defers the updates of several pivots (their factors stay alive: +100 VGPRs)
+#pragma unroll
+            for (int q = 0; q <= NR; ++q) __asm__ volatile("" : "+v"(Hr[q]));
+            wcqp::wave_lds_fence();
+        }
+        ok = pmin > 0.0;
+    }
+    // Hr[0..11] now holds row j of -(M^-1) on lanes j < 12, Hr[12] = y_j
+    double nu0, nu1;
+    {
+        double* yv = S + OFF_YV;
+        yv[j] = j < NR ? Hr[NR] : 0.0;
+        wcqp::wave_lds_fence();
+        double s0 = gt0, s1 = gt1;
+#pragma unroll
+        for (int r = 0; r < NR; r += 2) {
+            const double2 y2 = ld2(yv + r);
+            s0 = fma(c0[r], y2.x, s0); s0 = fma(c0[r + 1], y2.y, s0);
+            s1 = fma(c1[r], y2.x, s1); s1 = fma(c1[r + 1], y2.y, s1);
+        }
+        nu0 = -s0;
+        nu1 = var1 ? -s1 : 0.0;
+    }
+    wcqp::wave_lds_fence();
+
+    // ---------------- phase 6: joint-velocity bounds (qpOASES form), in the scaled variable -----------------
+    int st_code = ok ? WCQP_STATUS_SOLVED : WCQP_STATUS_NUMERIC;
+    int it = 0;
+    bool in_w0 = false, in_w1 = false;
+    double sig0 = 0.0, sig1 = 0.0;
+    const bool bnd1 = var1;
+    lo1 = bnd1 ? lo1 : -inf; hi1 = bnd1 ? hi1 : inf;
+    const bool need = !osqp_form && (fmax(nu0 - hi0, lo0 - nu0) > tol || (bnd1 && fmax(nu1 - hi1, lo1 - nu1) > tol));
+    const unsigned long long need_m = __ballot(need);
+    if (((need_m >> (16 * grp)) & 0xffffull) != 0ull && st_code == WCQP_STATUS_SOLVED) {
+        // Goldfarb-Idnani dual active set on columns of P = I - C' M^-1 C (see ik3.hip phase 5 for the scheme;
+        // the differences: a column tau_p costs one published column of C, a 12 x 12 product by rows and a
+        // column-local dot product; entries of tau_p at other variables travel by ds_bpermute).
+        double* cpv = S + OFF_CPV;
+        double* ypv = S + OFF_YPV;
+        double* tpb = S + OFF_TPB;
+        double* rvec = S + OFF_RV;
+        double* cvec = S + OFF_CV;
+        double* Rinv = S + OFF_RINV;
+        int* Wi = reinterpret_cast<int*>(S + OFF_WI);
+        const int rowbase = lane & 48;
+        bool pending = false;
+        int p = 0;
+        double sig = 0.0, s = 0.0, tp0 = 0.0, tp1 = 0.0, ppp = 1.0, mu_p = 0.0;
+        bool done = false;
+        int nW = 0;
+        constexpr int KS = 4;
+        double Rs[KS][KS], sgS[KS], muS[KS], tvS[KS], tc0[KS], tc1[KS];
+        int wS[KS];
+#pragma unroll
+        for (int a = 0; a < KS; ++a) {
+            sgS[a] = 0.0; muS[a] = 0.0; tvS[a] = 0.0; wS[a] = 0; tc0[a] = 0.0; tc1[a] = 0.0;
+#pragma unroll
+            for (int b = 0; b < KS; ++b) Rs[a][b] = 0.0;
+        }
+        auto most_violated = [&]() -> unsigned {
+            const double viol0 = !in_w0 ? fmax(nu0 - hi0, lo0 - nu0) : -inf;
+            const double viol1 = (bnd1 && !in_w1) ? fmax(nu1 - hi1, lo1 - nu1) : -inf;
+            const unsigned k0 = viol0 > tol ? (mag_key(viol0) | (unsigned)(31 - j)) : 0u;
+            const unsigned k1 = viol1 > tol ? (mag_key(viol1) | (unsigned)(15 - j)) : 0u;
+            return row_max_u32(max(k0, k1));
+        };
+        // value of variable w's entry of a per-variable pair (v0 on slot 0, v1 on slot 1), w uniform in the row
+        auto at_var = [&](double v0, double v1, int w) -> double {
+            return lane_gather(w >= 16 ? v1 : v0, (rowbase + (w & 15)) << 2);
+        };
+        // P v for a vector given by its entries on the own variables: v - C' M^-1 (C v); `single`: v = e_p (the
+        // owner publishes its column, no reduction)
+        auto apply_P = [&](double v0, double v1, double& z0, double& z1) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const double cvr = row_sum(fma(v0, c0[r], v1 * c1[r]));
+                t = fma(Hr[r], cvr, t);                   // -(M^-1 C v)_j on lanes j < 12
+            }
+            wcqp::wave_lds_fence();
+            ypv[j] = j < NR ? t : 0.0;
+            wcqp::wave_lds_fence();
+            z0 = v0; z1 = v1;
+#pragma unroll
+            for (int r = 0; r < NR; r += 2) {
+                const double2 y2 = ld2(ypv + r);
+                z0 = fma(c0[r], y2.x, z0); z0 = fma(c0[r + 1], y2.y, z0);
+                z1 = fma(c1[r], y2.x, z1); z1 = fma(c1[r + 1], y2.y, z1);
+            }
+        };
+        // makes the bound of `key` the pending one: p, sig, s, signed column tau_p, P[p][p]
+        auto enter = [&](unsigned key, bool general) {
+            ++it;
+            p = 31 - (int)(key & 31u);
+            const bool sl1 = p >= 16;
+            const double vh = sl1 ? nu1 - hi1 : nu0 - hi0, vl = sl1 ? lo1 - nu1 : lo0 - nu0;
+            const double sviol = vh >= vl ? vh : -vl;                                   // sign = side, |.| = violation
+            const int src = (rowbase + (p & 15)) << 2;
+            const double sv_p = lane_gather(sviol, src);
+            s = fabs(sv_p);
+            sig = sv_p >= 0.0 ? 1.0 : -1.0;
+            wcqp::wave_lds_fence();
+            if (j == (p & 15)) {
+#pragma unroll
+                for (int r = 0; r < NR; r += 2) st2(cpv + r, sl1 ? c1[r] : c0[r], sl1 ? c1[r + 1] : c0[r + 1]);
+            }
+            wcqp::wave_lds_fence();
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r += 2) {
+                const double2 c2 = ld2(cpv + r);
+                t = fma(Hr[r], c2.x, t); t = fma(Hr[r + 1], c2.y, t);
+            }
+            ypv[j] = j < NR ? t : 0.0;                                   // -(M^-1 c_p)_j
+            wcqp::wave_lds_fence();
+            double u0 = (p == j) ? 1.0 : 0.0, u1 = (p == col1) ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r += 2) {
+                const double2 y2 = ld2(ypv + r);
+                u0 = fma(c0[r], y2.x, u0); u0 = fma(c0[r + 1], y2.y, u0);
+                u1 = fma(c1[r], y2.x, u1); u1 = fma(c1[r + 1], y2.y, u1);
+            }
+            u1 = var1 ? u1 : 0.0;
+            ppp = lane_gather(sl1 ? u1 : u0, src);                       // P[p][p] > 0
+#pragma unroll
+            for (int a = 0; a < KS; ++a) tvS[a] = at_var(u0, u1, wS[a]);   // tau_p at the replicated working set
+            tp0 = sig * u0; tp1 = sig * u1;
+            if (general) { tpb[j] = tp0; tpb[col1] = tp1; }
+            mu_p = 0.0;
+            pending = true;
+        };
+        // First bound, empty working set, straight-line: full step along tau_p, the bound takes slot 0.
+        {
+            const unsigned key = most_violated();          // != 0: that is what `need` said
+            enter(key, false);
+            if (ppp > 0.0) {
+                const double inz = wcqp::fast_rcp(ppp);
+                const double t = s * inz;
+                nu0 = fma(-t, tp0, nu0);
+                nu1 = fma(-t, tp1, nu1);
+                wS[0] = p; sgS[0] = sig; muS[0] = t; Rs[0][0] = inz;
+                tc0[0] = tp0; tc1[0] = tp1;
+                if (p == j) { in_w0 = true; sig0 = sig; }
+                if (p == col1) { in_w1 = true; sig1 = sig; }
+                nW = 1;
+                pending = false;
+                done = most_violated() == 0u;
+            } else {
+                st_code = WCQP_STATUS_INFEASIBLE; done = true;
+            }
+        }
+        bool small = !done;
+#pragma unroll 1
+        for (int pass = 0; pass < 1024 && small; ++pass) {
+            if (!pending) {
+                if (nW >= KS) { small = false; break; }                      // a fifth bound: general loop
+                const unsigned key = most_violated();
+                if (key == 0u) { done = true; small = false; break; }
+                if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; small = false; break; }
+                enter(key, false);
+            }
+            double c[KS], r[KS];
+#pragma unroll
+            for (int a = 0; a < KS; ++a) c[a] = sgS[a] * sig * tvS[a];       // 0 on slots that are not live
+            double z0 = tp0, z1 = tp1, nzv = ppp, t1 = inf;
+            int jd = 0;
+#pragma unroll
+            for (int a = 0; a < KS; ++a) {
+                double ra = 0.0;
+#pragma unroll
+                for (int b = 0; b < KS; ++b) ra = fma(b >= a ? Rs[a][b] : Rs[b][a], c[b], ra);
+                r[a] = ra;
+                z0 = fma(-ra, tc0[a], z0);
+                z1 = fma(-ra, tc1[a], z1);
+                nzv = fma(-ra, c[a], nzv);
+            }
+#pragma unroll
+            for (int a = 0; a < KS; ++a) {
+                const double ratio = (sgS[a] != 0.0 && r[a] > 0.0) ? muS[a] * wcqp::fast_rcp(r[a]) : inf;
+                if (ratio < t1) { t1 = ratio; jd = a; }                      // ties: lowest slot
+            }
+            const double inz = wcqp::fast_rcp(nzv);
+            const double t2 = (nzv > 1e-10 * ppp) ? s * inz : inf;           // dependence shows as a vanishing Schur complement
+            const double t = fmin(t1, t2);
+            if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; done = true; small = false; break; }
+            nu0 = fma(-t, z0, nu0);
+            nu1 = fma(-t, z1, nu1);
+#pragma unroll
+            for (int a = 0; a < KS; ++a) muS[a] = fma(-t, r[a], muS[a]);
+            mu_p += t;
+            s -= t * nzv;
+            if (t2 <= t1) {
+                int n = KS - 1;
+#pragma unroll
+                for (int a = KS - 1; a >= 0; --a) n = (sgS[a] != 0.0) ? n : a;
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    const bool me = a == n;
+                    const double ra_inz = r[a] * inz;
+#pragma unroll
+                    for (int b = a; b < KS; ++b) {
+                        const double upd = fma(ra_inz, r[b], Rs[a][b]);
+                        Rs[a][b] = (b == n) ? (me ? inz : -ra_inz) : (me ? -r[b] * inz : upd);
+                    }
+                    wS[a] = me ? p : wS[a];
+                    sgS[a] = me ? sig : sgS[a];
+                    muS[a] = me ? mu_p : muS[a];
+                    tc0[a] = me ? tp0 : tc0[a];
+                    tc1[a] = me ? tp1 : tc1[a];
+                }
+                if (p == j) { in_w0 = true; sig0 = sig; }
+                if (p == col1) { in_w1 = true; sig1 = sig; }
+                ++nW;
+                pending = false;
+            } else {
+                int wdrop = 0;
+                double cj[KS];
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    wdrop = (a == jd) ? wS[a] : wdrop;
+                    cj[a] = 0.0;
+#pragma unroll
+                    for (int b = 0; b < KS; ++b) cj[a] = (b == jd) ? (b >= a ? Rs[a][b] : Rs[b][a]) : cj[a];   // column jd
+                }
+                double djj = 1.0;
+#pragma unroll
+                for (int a = 0; a < KS; ++a) djj = (a == jd) ? cj[a] : djj;
+                const double idj = wcqp::fast_rcp(djj);
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    const bool me = a == jd;
+                    const double fa = cj[a] * idj;
+#pragma unroll
+                    for (int b = a; b < KS; ++b) Rs[a][b] = (me || b == jd) ? 0.0 : fma(-fa, cj[b], Rs[a][b]);
+                    sgS[a] = me ? 0.0 : sgS[a];
+                    muS[a] = me ? 0.0 : muS[a];
+                }
+                if (wdrop == j) { in_w0 = false; sig0 = 0.0; }
+                if (wdrop == col1) { in_w1 = false; sig1 = 0.0; }
+                --nW;
+                ++it;
+            }
+        }
+        if (!done) {
+            // ---- working sets of more than KS bounds: slot a is owned by lane a, row a of the explicit inverse of
+            // the active-bound system sits in LDS; the primal step is P applied to the sparse vector
+            // sig e_p - sum_a r_a sigma_a e_{w_a} (no stored columns: registers are what this kernel saves)
+            bool s_live = false;
+            int s_var = 0;
+            double s_sg = 0.0, s_mu = 0.0;
+            int slot0 = 0, slot1 = 0;                   // slot of the own variables while they are in the working set
+            double* myR = Rinv + (j < KMAX ? j : 0) * LDR;
+            {
+                double myrow[KS];
+#pragma unroll
+                for (int b = 0; b < KS; ++b) {
+                    myrow[b] = 0.0;
+#pragma unroll
+                    for (int a = 0; a < KS; ++a) myrow[b] = (a == j) ? (b >= a ? Rs[a][b] : Rs[b][a]) : myrow[b];
+                }
+                wcqp::wave_lds_fence();
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    if (a == j) { s_live = sgS[a] != 0.0; s_var = wS[a]; s_sg = sgS[a]; s_mu = muS[a]; Wi[a] = wS[a]; }
+                    if (sgS[a] != 0.0 && wS[a] == j) slot0 = a;
+                    if (sgS[a] != 0.0 && wS[a] == col1) slot1 = a;
+                }
+                if (j < KMAX) {
+#pragma unroll
+                    for (int b = 0; b < KMAX; ++b) myR[b] = (b < KS) ? myrow[b < KS ? b : 0] : 0.0;
+                }
+                if (pending) { tpb[j] = tp0; tpb[col1] = tp1; }
+                wcqp::wave_lds_fence();
+            }
+#pragma unroll 1
+            for (int pass = 0; pass < 1024 && !done; ++pass) {
+                if (!pending) {
+                    const unsigned key = most_violated();
+                    if (key == 0u) { done = true; }
+                    else if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; }
+                    else { enter(key, true); wcqp::wave_lds_fence(); }
+                }
+                if (!done) {
+                    // dual step r = Rinv c,  c_a = sigma_a tau_p[w_a]
+                    cvec[j] = s_live ? s_sg * tpb[s_var] : 0.0;
+                    wcqp::wave_lds_fence();
+                    double r_a = 0.0;
+#pragma unroll
+                    for (int b = 0; b < KMAX; b += 2) {
+                        const double2 c2 = ld2(cvec + b);
+                        r_a = fma(myR[b], c2.x, r_a);
+                        r_a = fma(myR[b + 1], c2.y, r_a);
+                    }
+                    r_a = s_live ? r_a : 0.0;
+                    rvec[j] = r_a;
+                    wcqp::wave_lds_fence();
+                    // primal step z = P (sig e_p - sum_a r_a sigma_a e_{w_a})
+                    const double v0 = ((p == j) ? sig : 0.0) - (in_w0 ? rvec[slot0] * sig0 : 0.0);
+                    const double v1 = ((p == col1) ? sig : 0.0) - (in_w1 ? rvec[slot1] * sig1 : 0.0);
+                    double z0, z1;
+                    apply_P(v0, v1, z0, z1);
+                    z1 = var1 ? z1 : 0.0;
+                    const double nzv = sig * at_var(z0, z1, p);              // Schur complement of the bordered system
+                    const double ratio = (s_live && r_a > 0.0) ? s_mu * wcqp::fast_rcp(r_a) : inf;
+                    const double t1 = row_min(ratio);
+                    const double inz = wcqp::fast_rcp(nzv);
+                    const double t2 = (nW < KMAX && nzv > 1e-10 * ppp) ? s * inz : inf;
+                    const double t = fmin(t1, t2);
+                    if (!(t < inf)) { st_code = WCQP_STATUS_INFEASIBLE; done = true; }
+                    else {
+                        nu0 = fma(-t, z0, nu0);
+                        nu1 = fma(-t, z1, nu1);
+                        s_mu = s_live ? s_mu - t * r_a : s_mu;
+                        mu_p += t;
+                        s -= t * nzv;
+                        if (t2 <= t1) {
+                            // full step: p enters the first free slot; Rinv <- bordered inverse
+                            const unsigned fm = (unsigned)((__ballot(j < KMAX && !s_live) >> (16 * grp)) & 0xffffull);
+                            const int n = fm ? __ffs(fm) - 1 : 0;
+                            const double ra_inz = r_a * inz;         // 0 on lanes without a live slot
+                            const bool me = j == n;
+#pragma unroll
+                            for (int b = 0; b < KMAX; b += 2) {
+                                const double2 r2 = ld2(rvec + b);
+                                const double u0 = me ? -r2.x * inz : fma(ra_inz, r2.x, myR[b]);
+                                const double u1 = me ? -r2.y * inz : fma(ra_inz, r2.y, myR[b + 1]);
+                                if (j < KMAX) { myR[b] = u0; myR[b + 1] = u1; }
+                            }
+                            wcqp::wave_lds_fence();
+                            if (j < KMAX) myR[n] = me ? inz : -ra_inz;
+                            if (me) { s_live = true; s_var = p; s_sg = sig; s_mu = mu_p; Wi[n] = p; }
+                            if (p == j) { in_w0 = true; sig0 = sig; slot0 = n; }
+                            if (p == col1) { in_w1 = true; sig1 = sig; slot1 = n; }
+                            ++nW;
+                            pending = false;
+                        } else {
+                            // partial step: the blocking constraint leaves the working set; Rinv <- downdated inverse
+                            const unsigned dm = (unsigned)((__ballot(ratio == t1) >> (16 * grp)) & 0xffffull);
+                            const int jd = dm ? __ffs(dm) - 1 : 0;
+                            const int wdrop = Wi[jd];
+                            const double* dR = Rinv + jd * LDR;
+                            const double djj = dR[jd];
+                            const double f = (s_live && j != jd) ? dR[j < KMAX ? j : 0] * wcqp::fast_rcp(djj) : 0.0;      // Rinv is symmetric
+                            double u[KMAX];
+#pragma unroll
+                            for (int b = 0; b < KMAX; ++b) u[b] = (j == jd) ? 0.0 : fma(-f, dR[b], myR[b]);
+                            wcqp::wave_lds_fence();
+                            if (j < KMAX) {
+#pragma unroll
+                                for (int b = 0; b < KMAX; ++b) myR[b] = u[b];
+                                myR[jd] = 0.0;
+                            }
+                            if (j == jd) { s_live = false; s_mu = 0.0; }
+                            if (wdrop == j) { in_w0 = false; sig0 = 0.0; }
+                            if (wdrop == col1) { in_w1 = false; sig1 = 0.0; }
+                            --nW;
+                            ++it;
+                        }
+                    }
+                }
+                wcqp::wave_lds_fence();
+            }
+        }
+        // certificate: every bound holds and every active bound is tight, else the walk lost accuracy
+        {
+            const double d0 = in_w0 ? fabs(nu0 - (sig0 > 0.0 ? hi0 : lo0)) : fmax(nu0 - hi0, lo0 - nu0);
+            const double d1 = !bnd1 ? 0.0 : (in_w1 ? fabs(nu1 - (sig1 > 0.0 ? hi1 : lo1)) : fmax(nu1 - hi1, lo1 - nu1));
+            const double dev = fmax(d0 == d0 ? d0 : inf, d1 == d1 ? d1 : inf);
+            const unsigned bad = row_max_u32((dev > 1e-9) ? 1u : 0u);
+            if (st_code == WCQP_STATUS_SOLVED && bad != 0u) st_code = WCQP_STATUS_NUMERIC;
+        }
+    }
+
+    // ---------------- outputs (back in the unscaled variable) ----------------------------------------------
+    double dq0 = nu0 * sd0, dq1 = nu1 * sd1;
+    if (st_code == WCQP_STATUS_SOLVED && in_w0) dq0 = sig0 > 0.0 ? prm->vhi[v0i] : prm->vlo[v0i];
+    if (st_code == WCQP_STATUS_SOLVED && in_w1) dq1 = sig1 > 0.0 ? prm->vhi[v1i] : prm->vlo[v1i];
+    const unsigned long long bu0 = __ballot(in_w0 && sig0 > 0.0), bu1 = __ballot(in_w1 && sig1 > 0.0);
+    const unsigned long long bl0 = __ballot(in_w0 && sig0 < 0.0), bl1 = __ballot(in_w1 && sig1 < 0.0);
+    if (!use) {
+        // not MIXED-form Jacobians: say so (the dispatcher then runs the general kernel over the flagged instances)
+        st_code = WCQP_STATUS_STRUCTURE;
+        dq0 = 0.0; dq1 = 0.0;
+    }
+    if (live) {
+        dq_out[inst * kDof + j] = dq0;
+        if (var1) dq_out[inst * kDof + col1] = dq1;
+        if (j == 0) {
+            const unsigned up = (unsigned)((bu0 >> (16 * grp)) & 0xffffull) | ((unsigned)((bu1 >> (16 * grp)) & 0x7full) << 16);
+            const unsigned dn = (unsigned)((bl0 >> (16 * grp)) & 0xffffull) | ((unsigned)((bl1 >> (16 * grp)) & 0x7full) << 16);
+            status_out[inst] = st_code;
+            if (aup_out) aup_out[inst] = use ? up : 0u;
+            if (alo_out) alo_out[inst] = use ? dn : 0u;
+            if (iters_out) iters_out[inst] = it;
+        }
+    }
+    if constexpr (TICK) {
+        const bool ik_ok = st_code == WCQP_STATUS_SOLVED;
+        if (live) {
+            const int i_ = (int)inst;
+            wcqp_tick::tick_post_joint(td, i_, tick_now, j, ik_ok, dq0);
+            if (var1) wcqp_tick::tick_post_joint(td, i_, tick_now, col1, ik_ok, dq1);
+            if (j == 0) wcqp_tick::tick_post_instance(td, i_, tick_now, ik_ok);
+        }
+        // advanceReferenceSignals (WalkingModule.cpp:816): every kernel after the MPC reads the tick index
+        // from the copy the MPC kernel made, so `tick` itself may advance as soon as this kernel runs
+        if (blockIdx.x == 0 && lane == 0) *td.tick = tick_now + 1;
+    }
+    if (ferr_out) {
+        // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401) with nu = (v_base, dq) and
+        // v_base = X_L^-1 (b_L - J_Lq dq): every lane multiplies its joint columns (reloaded, L2-resident) by its
+        // velocities, a [12][18] LDS tile turns the 16 partial sums of a row over to lane r
+        double* pb = S + OFF_PB;
+        double* uv = S + OFF_YV;
+        const int fc0 = 6 + j, fc1 = var1 ? 22 + j : 6;
+        const double v1 = var1 ? dq1 : 0.0;
+        const double* jl = JL + inst * (6 * kNV);
+        const double* jr = JR + inst * (6 * kNV);
+        double part[12];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            part[r] = fma(jl[r * kNV + fc0], dq0, jl[r * kNV + fc1] * v1);
+            part[6 + r] = fma(jr[r * kNV + fc0], dq0, jr[r * kNV + fc1] * v1);
+        }
+        wcqp::wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 12; ++r) pb[r * 18 + j] = part[r];
+        wcqp::wave_lds_fence();
+        double u_mine = 0.0;
+        if (j < 12) {
+            u_mine = b_mine;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) { const double2 p2 = ld2(pb + j * 18 + k); u_mine -= p2.x; u_mine -= p2.y; }
+            uv[j] = u_mine;                       // b - J_q dq by row
+        }
+        wcqp::wave_lds_fence();
+        if (j < 12 && live && use) {
+            const int rr = j % 6, foot = j / 6;
+            const double wa0 = uv[3], wa1 = uv[4], wa2 = uv[5];          // base angular velocity
+            double jv;                                                  // row j of [X_L; X_R] v_base
+            if (rr < 3) {
+                const double* bl = jl + rr * kNV + 3;
+                const double* bf = (foot ? jr : jl) + rr * kNV + 3;
+                const double vlin = uv[rr] - (bl[0] * wa0 + bl[1] * wa1 + bl[2] * wa2);
+                jv = vlin + (bf[0] * wa0 + bf[1] * wa1 + bf[2] * wa2);
+            } else {
+                jv = uv[rr];
+            }
+            ferr_out[inst * 12 + j] = u_mine - jv;
+        }
+    }
+}
+
+}  // namespace
+
+namespace wcqp_ik {
+
+int ik4_launch(const IkDeviceParams* d_prm, int batch,
+               const double* JL, const double* JR, const double* JN, const double* JC,
+               const double* q, const double* state, double* dq, int* status,
+               unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
+    const unsigned grid = (unsigned)((batch + 3) / 4);
+    hipLaunchKernelGGL(ik4_kernel<false>, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+                       dq, status, alo, aup, ferr, iters, wcqp_tick::TickDev{});
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
+                    const double* JL, const double* JR, const double* JN, const double* JC,
+                    unsigned* alo, unsigned* aup, hipStream_t stream) {
+    if (!d_prm) return WCQP_E_INVALID;
+    const unsigned grid = (unsigned)((td.batch + 3) / 4);
+    hipLaunchKernelGGL(ik4_kernel<true>, dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
+                       JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+}  // namespace wcqp_ik

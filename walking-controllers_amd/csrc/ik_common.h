@@ -17,6 +17,10 @@ struct IkDeviceParams {
     double Wn[9], Wc[9];
     double k_pos_com, k_pos_foot, k_att_foot, k_neck, kappa, rho, tol;
     int form, max_iter;
+    // base-eliminated kernel (ik4.hip), indexed by JOINT column c = 0..22 (entries 23..31: 1.0 / 0.0)
+    double sd[32], isd[32];    // sqrt(1 / Lambda_c), sqrt(Lambda_c): column scaling that turns Lambda into I
+    double Lt[9];              // L' (row-major, upper triangular) of the neck weight W = L L'
+    int fast_ok;               // CoM as constraint, every Lambda_c > 0, W positive definite
 };
 
 // rotation error component k of unskew(0.5 (E - E')), E = R Rd'     Utils.cpp:22-27
@@ -122,6 +126,37 @@ __device__ __forceinline__ double lane_gather(double v, int src_byte) {
     const int hi = __builtin_amdgcn_ds_bpermute(src_byte, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+
+// all-reduce over the 16 lanes of a DPP row
+__device__ __forceinline__ unsigned row_max_u32(unsigned key) {
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x141, 0xf, 0xf, false));
+    key = max(key, (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x140, 0xf, 0xf, false));
+    return key;
+}
+__device__ __forceinline__ double row_min(double v) {
+    v = fmin(v, dpp_move<0xB1>(v));
+    v = fmin(v, dpp_move<0x4E>(v));
+    v = fmin(v, dpp_move<0x141>(v));
+    v = fmin(v, dpp_move<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ double row_max(double v) {
+    v = fmax(v, dpp_move<0xB1>(v));
+    v = fmax(v, dpp_move<0x4E>(v));
+    v = fmax(v, dpp_move<0x141>(v));
+    v = fmax(v, dpp_move<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned mag_key(double v) { return __float_as_uint((float)fabs(v)) & ~31u; }
 
 // lowest lane of this 32-lane group whose predicate holds (32 if none)
 __device__ __forceinline__ int group_first(bool pred, int half) {
@@ -326,12 +361,27 @@ int ik3_launch(const IkDeviceParams* d_prm, int batch,
                const double* q, const double* state, double* dq, int* status,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream);
 
+// launch of the base-eliminated range-space kernel (ik4.hip; MIXED free-floating Jacobians, CoM as constraint).
+// Instances whose base blocks do not have the MIXED pattern come back with status WCQP_STATUS_STRUCTURE and dq = 0.
+int ik4_launch(const IkDeviceParams* d_prm, int batch,
+               const double* JL, const double* JR, const double* JN, const double* JC,
+               const double* q, const double* state, double* dq, int* status,
+               unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream);
+// the general 16-lane kernel over the instances whose status reads WCQP_STATUS_STRUCTURE
+int ik3_launch_list(const IkDeviceParams* d_prm, int batch,
+                    const double* JL, const double* JR, const double* JN, const double* JC,
+                    const double* q, const double* state, double* dq, int* status,
+                    unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream);
+
 }  // namespace wcqp_ik
 
 namespace wcqp_tick { struct TickDev; }
 namespace wcqp_ik {
 // the 16-lane kernel with the tick pipeline's glue and post steps fused in (tick.hip)
 int ik3_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
+                    const double* JL, const double* JR, const double* JN, const double* JC,
+                    unsigned* alo, unsigned* aup, hipStream_t stream);
+int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
                     const double* JL, const double* JR, const double* JN, const double* JC,
                     unsigned* alo, unsigned* aup, hipStream_t stream);
 }  // namespace wcqp_ik

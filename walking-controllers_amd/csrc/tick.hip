@@ -62,6 +62,7 @@ struct wcqp_tick_s {
     hipStream_t graph_stream = nullptr;
     bool uploaded = false;
     bool fused = false;      // glue + post inside the 16-lane IK kernel: 2 launches per tick instead of 4
+    bool base_elim = false;  // the fused kernel is the base-eliminated one (ik4.hip)
 };
 
 namespace {
@@ -84,6 +85,9 @@ int enqueue_tick(wcqp_tick_s* h, hipStream_t s) {
                                d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, 3, d.sel,
                                d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
     if (rc != WCQP_OK) return rc;
+    if (h->fused && h->base_elim)
+        return wcqp_ik::ik4_launch_tick(wcqp::ik_device_params(h->ik), d, h->J_left, h->J_right, h->J_neck, h->J_com,
+                                        h->ik_lo, h->ik_up, s);
     if (h->fused)
         return wcqp_ik::ik3_launch_tick(wcqp::ik_device_params(h->ik), d, h->J_left, h->J_right, h->J_neck, h->J_com,
                                         h->ik_lo, h->ik_up, s);
@@ -115,12 +119,17 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     // the fused form exists for the 16-lane kernel only (CoM as constraint); an explicit 32-lane / sweep
     // algorithm keeps the four-launch form, which is also what the fused one is tested against
     h->fused = params->ik.use_com_as_constraint &&
-               (params->ik.algorithm == WCQP_IK_ALG_DEFAULT || params->ik.algorithm == WCQP_IK_ALG_NULLSPACE_16L);
+               (params->ik.algorithm == WCQP_IK_ALG_DEFAULT || params->ik.algorithm == WCQP_IK_ALG_NULLSPACE_16L ||
+                params->ik.algorithm == WCQP_IK_ALG_BASE_ELIM);
     int rc = wcqp_mpc_create(&params->mpc, &h->mpc);
     if (rc == WCQP_OK) rc = wcqp_ik_create(&params->ik, &h->ik);
     if (rc == WCQP_OK) rc = wcqp::mpc_prepare(h->mpc);
     if (rc == WCQP_OK) rc = wcqp::ik_prepare(h->ik);
     if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
+    // the tick's Jacobians are MIXED free-floating ones (uploaded or from wcqp_kin_*): an instance that is not comes
+    // back WCQP_STATUS_STRUCTURE and counts as an IK failure
+    h->base_elim = h->fused && params->ik.algorithm != WCQP_IK_ALG_NULLSPACE_16L &&
+                   params->ik.jacobian_structure != WCQP_IK_JAC_GENERAL && wcqp::ik_fast_ok(h->ik);
     const size_t B = (size_t)params->batch;
     const int N = params->mpc.horizon;
     TickDev& d = h->d;

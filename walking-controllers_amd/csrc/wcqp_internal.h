@@ -39,6 +39,7 @@ int mpc_horizon(wcqp_mpc_t h);
 int mpc_prepare(wcqp_mpc_t h);     // uploads the handle's device constants now (graph capture forbids it later)
 int ik_prepare(wcqp_ik_t h);
 const void* ik_device_params(wcqp_ik_t h);     // IkDeviceParams* in HBM (after ik_prepare)
+bool ik_fast_ok(wcqp_ik_t h);                  // the handle qualifies for the base-eliminated kernel (ik4.hip)
 void mpc_dynamics(wcqp_mpc_t h, double* a, double* b);
 
 // ---- wave-level helpers used by the kernels (gfx950, wave64) -------------------------
