@@ -28,10 +28,14 @@
 //
 // Lane j of an instance's 16 owns joint column j (slot 0) and, in slot 1: joint column 16 + j (j < 7), the
 // right-hand-side column [b_L; b_R; b_C; e_neck] (j = 7), base column j - 8 (j = 8 .. 13: pattern check and B blocks).
-// LDS 408 doubles per instance (13 KB per block: 12 blocks per CU = 3 waves per SIMD).
+// C^T (k-major) stays in LDS from the Gram product to the end: the columns are re-read where they are needed (x~,
+// a bound's column tau_p) instead of occupying 48 VGPRs through the sweep, and the Gram tile reaches its row lanes
+// through v_permlane32_swap / v_permlane16_swap (a 4 x 4 block transpose across the wave's four DPP rows) instead of
+// an LDS tile.  LDS 408 doubles per instance (13 KB per block: 12 blocks per CU = 3 waves per SIMD).
 // Template parameter TICK: the tick pipeline's glue / post steps fused in (tick_device.h).
 #include <cmath>
 #include <limits>
+#include <type_traits>
 #include "ik_common.h"
 #include "tick_device.h"
 
@@ -54,31 +58,49 @@ constexpr int LDC = 14;               // leading dimension of C^T (k-major) and 
 constexpr int OFF_ST = 0;             // [112] state + q
 constexpr int OFF_BV = 112;           // [18]  task rhs b (15) and neck target e (3)
 constexpr int OFF_DB = 130;           // [18]  B_R - B_L, B_C - B_L (row-major 3x3 each)
-//   Gram
+//   Gram .. end
 constexpr int OFF_CT = 0;             // [24][LDC] (+2): C^T k-major, row 12 = g~, row 13 = 0; k = 23: zero column
-constexpr int OFF_TILE = 0;           // [16][LDC] Gram tile
-//   active set
-constexpr int OFF_CPV = 0;            // [16] column p of C
-constexpr int OFF_YPV = 16;           // [16] M^-1 C v
-constexpr int OFF_TPB = 32;           // [32] signed column tau_p by variable
-constexpr int OFF_RV = 64;            // [16] dual step per slot
-constexpr int OFF_CV = 80;            // [16]
-constexpr int OFF_WI = 96;            // [16] ints: variable of slot a
-constexpr int OFF_RINV = 104;         // [KMAX][LDR]
 constexpr int OFF_PB = 0;             // [12][18] foot-error partial products (epilogue)
 constexpr int A_SIZE = 340;
 // region B
 constexpr int OFF_COL = A_SIZE;       // [2][16] sweep columns
 constexpr int OFF_YV = A_SIZE + 32;   // [16] y
 constexpr int OFF_DV = A_SIZE + 48;   // [16] d = [t; b'] by row
-constexpr int PER_INST = 408;         // = 24 mod 32: the four instances of a wave sit 16 banks apart
-static_assert(OFF_CT + 24 * LDC + 2 <= A_SIZE && OFF_RINV + KMAX * LDR <= A_SIZE && OFF_DB + 18 <= A_SIZE, "LDS overlays");
-static_assert(OFF_DV + 16 <= PER_INST && (PER_INST % 32 == 24 || PER_INST % 32 == 8), "instances 16 banks apart");
+//   active set (region B is dead after x~)
+constexpr int OFF_YPV = A_SIZE;       // [16] M^-1 C v
+constexpr int OFF_RV = A_SIZE + 16;   // [16] dual step per slot      (working sets of more than KS bounds)
+constexpr int OFF_CV = A_SIZE + 32;   // [16]
+constexpr int OFF_ROWB = A_SIZE + 48; // [16] row of the leaving slot
+constexpr int OFF_WI = A_SIZE + 64;   // [16] ints: variable of slot a
+constexpr int PER_INST = 424;         // = 8 mod 32: the four instances of a wave sit 16 banks apart
+static_assert(OFF_CT + 24 * LDC + 2 <= A_SIZE && OFF_DB + 18 <= A_SIZE && OFF_PB + 12 * 18 <= A_SIZE, "LDS overlays");
+static_assert(OFF_WI + 8 <= PER_INST && OFF_DV + 16 <= PER_INST && (PER_INST % 32 == 24 || PER_INST % 32 == 8), "instances 16 banks apart");
 static_assert(PER_INST * 8 * 4 * 12 <= 160 * 1024, "12 blocks per CU");
 
 #ifndef WCQP_IK4_WAVES
 #define WCQP_IK4_WAVES 2
 #endif
+
+#ifdef WCQP_IK_STAMPS
+#define WCQP_STAMP(k) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+                           if (lane == __ffsll((long long)__ballot(true)) - 1) reinterpret_cast<unsigned long long*>(ferr_out)[(size_t)blockIdx.x * 16 + (k)] = t__; } while (0)
+#else
+#define WCQP_STAMP(k) do { } while (0)
+#endif
+
+// (a, b) -> (rows {a0, a1, b0, b1}, rows {a2, a3, b2, b3}) of the four 16-lane rows (checked on the GPU:
+// tools/ubench/permlane_test.hip)
+__device__ __forceinline__ void swap32(double& a, double& b) {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]); b = __hiloint2double((int)h[1], (int)l[1]);
+}
+// (a, b) -> (rows {a0, b0, a2, b2}, rows {a1, b1, a3, b3})
+__device__ __forceinline__ void swap16(double& a, double& b) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]); b = __hiloint2double((int)h[1], (int)l[1]);
+}
 
 __device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
@@ -112,6 +134,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     int tick_now = 0;
     if constexpr (TICK) tick_now = *td.tick_latched;
 
+    WCQP_STAMP(0);
     // ---------------- phase 0: loads ------------------------------------------------------------
     const int v0i = 6 + j, v1i = var1 ? 22 + j : 0;           // index into the per-variable constant tables
     const double sd0 = prm->sd[j], sd1 = prm->sd[col1], isd0 = prm->isd[j], isd1 = prm->isd[col1];
@@ -169,6 +192,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
     wcqp::wave_lds_fence();
 
+    WCQP_STAMP(1);
     // ---------------- phase 1: task rhs b (lanes 0..14) and neck target e (lanes 13..15) ------------------
     double b_mine = 0.0;
     {
@@ -203,6 +227,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         for (int r = 0; r < NROWS_IN; r += 2) { const double2 b2 = ld2(bv + r); a1[r] = b2.x; a1[r + 1] = b2.y; }
     }
 
+    WCQP_STAMP(2);
     // ---------------- phase 2: base blocks: MIXED pattern check, B_R - B_L, B_C - B_L ---------------------
     bool pat = true;
     {
@@ -225,42 +250,39 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const bool use = fast_ok != 0 && ((__ballot(!pat) >> (16 * grp)) & 0xffffull) == 0ull;
     wcqp::wave_lds_fence();
 
-    // ---------------- phase 3: row operations on the own columns -> C (scaled) -------------------------------
-    double c0[NR], c1[NR];
-    {
-        const double* db = S + OFF_DB;
-        double dBR[9], dBC[9];
-#pragma unroll
-        for (int m = 0; m < 8; m += 2) { const double2 v = ld2(db + m); dBR[m] = v.x; dBR[m + 1] = v.y; }
-        { const double2 v = ld2(db + 8); dBR[8] = v.x; dBC[0] = v.y; }
-#pragma unroll
-        for (int m = 1; m < 9; m += 2) { const double2 v = ld2(db + 9 + m); dBC[m] = v.x; dBC[m + 1] = v.y; }
-        const double L00 = prm->Lt[0], L01 = prm->Lt[1], L02 = prm->Lt[2], L11 = prm->Lt[4], L12 = prm->Lt[5], L22 = prm->Lt[8];
-        auto xf = [&](const double (&a)[NROWS_IN], double sc, double (&c)[NR]) {
-            const double w0 = a[3], w1 = a[4], w2 = a[5];
-            const double n0 = a[15] - w0, n1 = a[16] - w1, n2 = a[17] - w2;
-            c[0] = sc * (L00 * n0 + L01 * n1 + L02 * n2);
-            c[1] = sc * (L11 * n1 + L12 * n2);
-            c[2] = sc * (L22 * n2);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                c[3 + r] = sc * (a[6 + r] - a[r] - (dBR[3 * r] * w0 + dBR[3 * r + 1] * w1 + dBR[3 * r + 2] * w2));
-                c[9 + r] = sc * (a[12 + r] - a[r] - (dBC[3 * r] * w0 + dBC[3 * r + 1] * w1 + dBC[3 * r + 2] * w2));
-            }
-            c[6] = sc * (a[9] - w0); c[7] = sc * (a[10] - w1); c[8] = sc * (a[11] - w2);
-        };
-        xf(a0, sd0, c0);
-        xf(a1, var1 ? sd1 : 1.0, c1);
-        if (!(var1 || rhs1)) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) c1[r] = 0.0;
-        }
-    }
-    wcqp::wave_lds_fence();           // ST / BV / DB are dead: C^T overlays them
-
-    // ---------------- phase 4: M = C C' + diag(I3, 0) and C g~ on one fp64 MFMA tile per instance ----------
+    WCQP_STAMP(3);
+    // ---------------- phase 3: row operations on the own columns -> C (scaled), straight into LDS -----------
     double Hr[NR + 1];
     {
+        double c0[NR], c1[NR];
+        {
+            const double* db = S + OFF_DB;
+            double dBR[9], dBC[9];
+#pragma unroll
+            for (int m = 0; m < 8; m += 2) { const double2 v = ld2(db + m); dBR[m] = v.x; dBR[m + 1] = v.y; }
+            { const double2 v = ld2(db + 8); dBR[8] = v.x; dBC[0] = v.y; }
+#pragma unroll
+            for (int m = 1; m < 9; m += 2) { const double2 v = ld2(db + 9 + m); dBC[m] = v.x; dBC[m + 1] = v.y; }
+            const double L00 = prm->Lt[0], L01 = prm->Lt[1], L02 = prm->Lt[2], L11 = prm->Lt[4], L12 = prm->Lt[5], L22 = prm->Lt[8];
+            auto xf = [&](const double (&a)[NROWS_IN], double sc, double (&c)[NR]) {
+                const double w0 = a[3], w1 = a[4], w2 = a[5];
+                const double n0 = a[15] - w0, n1 = a[16] - w1, n2 = a[17] - w2;
+                c[0] = sc * (L00 * n0 + L01 * n1 + L02 * n2);
+                c[1] = sc * (L11 * n1 + L12 * n2);
+                c[2] = sc * (L22 * n2);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    c[3 + r] = sc * (a[6 + r] - a[r] - (dBR[3 * r] * w0 + dBR[3 * r + 1] * w1 + dBR[3 * r + 2] * w2));
+                    c[9 + r] = sc * (a[12 + r] - a[r] - (dBC[3 * r] * w0 + dBC[3 * r + 1] * w1 + dBC[3 * r + 2] * w2));
+                }
+                c[6] = sc * (a[9] - w0); c[7] = sc * (a[10] - w1); c[8] = sc * (a[11] - w2);
+            };
+            xf(a0, sd0, c0);
+            xf(a1, var1 ? sd1 : 1.0, c1);
+        }
+        wcqp::wave_lds_fence();           // ST / BV / DB are dead: C^T overlays them
+        WCQP_STAMP(4);
+        // ---------------- phase 4: M = C C' + diag(I3, 0) and C g~ on one fp64 MFMA tile per instance ------
         double* ct = S + OFF_CT;
         double* dv = S + OFF_DV;
         {
@@ -278,11 +300,12 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         if (rhs1) {
 #pragma unroll
             for (int r = 0; r < NR; r += 2) st2(dv + r, c1[r], c1[r + 1]);
-#pragma unroll
-            for (int r = 0; r < NR; ++r) c1[r] = 0.0;
-            ct[24 * LDC] = 0.0; ct[24 * LDC + 1] = 0.0;   // read by tile rows 14, 15 of the last k (ignored, but keep them finite)
+            ct[24 * LDC] = 0.0; ct[24 * LDC + 1] = 0.0;   // read as tile rows 14, 15 of the last k (ignored, but keep them finite)
         }
-        wcqp::wave_lds_fence();
+    }
+    wcqp::wave_lds_fence();
+    WCQP_STAMP(10);
+    {
         const int mk = lane & 15, mq = lane >> 4;
         v4d acc[4];
 #pragma unroll
@@ -295,29 +318,33 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc[g], 0, 0, 0);
             }
         }
-        wcqp::wave_lds_fence();
-        // C/D layout of the f64 tile: col = lane & 15, row = (lane >> 4) + 4 * reg
+        WCQP_STAMP(11);
+        // C/D layout of the f64 tile: col = lane & 15, row = (lane >> 4) + 4 * reg, instance g in acc[g] on all four
+        // DPP rows.  4 x 4 block transpose across the rows: afterwards DPP row g holds instance g's tile, lane j its
+        // column j (= row j: M is symmetric), entry kb + 4 reg in t[kb][reg].
+        double t[4][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) smem[g][OFF_TILE + (mq + 4 * reg) * LDC + mk] = acc[g][reg];
+        for (int reg = 0; reg < 4; ++reg) {
+            double x0 = acc[0][reg], x1 = acc[1][reg], x2 = acc[2][reg], x3 = acc[3][reg];
+            swap32(x0, x2); swap32(x1, x3);      // x0: {inst 0 | inst 2} from source rows 0, 1;  x2: same from source rows 2, 3
+            swap16(x0, x1); swap16(x2, x3);      // x0: source row 0, x1: source row 1, x2: source row 2, x3: source row 3
+            t[0][reg] = x0; t[1][reg] = x1; t[2][reg] = x2; t[3][reg] = x3;
         }
-        wcqp::wave_lds_fence();
         // row j of [M | r] on lane j < 12, r' on lane 12 (the sweep treats it as one more row), zero rows above
-        const double* trow = S + OFF_TILE + j * LDC;
+        const double* dv = S + OFF_DV;
         const bool rowok = j < NR, is12 = j == NR;
         const double dj = dv[j < NR ? j : 0];
 #pragma unroll
         for (int k = 0; k < NR; k += 2) {
-            const double2 h2 = ld2(trow + k);
             const double2 d2 = ld2(dv + k);
-            Hr[k] = rowok ? h2.x + ((k == j && k < 3) ? 1.0 : 0.0) : (is12 ? -(h2.x + d2.x) : 0.0);
-            Hr[k + 1] = rowok ? h2.y + ((k + 1 == j && k + 1 < 3) ? 1.0 : 0.0) : (is12 ? -(h2.y + d2.y) : 0.0);
+            const double h0 = t[k & 3][k >> 2], h1 = t[(k + 1) & 3][(k + 1) >> 2];
+            Hr[k] = rowok ? h0 + ((k == j && k < 3) ? 1.0 : 0.0) : (is12 ? -(h0 + d2.x) : 0.0);
+            Hr[k + 1] = rowok ? h1 + ((k + 1 == j && k + 1 < 3) ? 1.0 : 0.0) : (is12 ? -(h1 + d2.y) : 0.0);
         }
-        Hr[NR] = rowok ? -(trow[NR] + dj) : 0.0;
+        Hr[NR] = rowok ? -(t[NR & 3][NR >> 2] + dj) : 0.0;
     }
-    wcqp::wave_lds_fence();
 
+    WCQP_STAMP(5);
     // bounds and active-set settings: fetched here so that the latency hides under the sweep
     const double tol = prm->tol;
     const int max_iter = prm->max_iter;
@@ -356,7 +383,11 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         }
         ok = pmin > 0.0;
     }
+    WCQP_STAMP(6);
     // Hr[0..11] now holds row j of -(M^-1) on lanes j < 12, Hr[12] = y_j
+    // the own columns of C, in LDS (slot 1 of the lanes without a second joint reads the zero column k = 23)
+    const double* ct0 = S + OFF_CT + j * LDC;
+    const double* ct1 = S + OFF_CT + (var1 ? col1 : 23) * LDC;
     double nu0, nu1;
     {
         double* yv = S + OFF_YV;
@@ -366,14 +397,16 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
         for (int r = 0; r < NR; r += 2) {
             const double2 y2 = ld2(yv + r);
-            s0 = fma(c0[r], y2.x, s0); s0 = fma(c0[r + 1], y2.y, s0);
-            s1 = fma(c1[r], y2.x, s1); s1 = fma(c1[r + 1], y2.y, s1);
+            const double2 a2 = ld2(ct0 + r), b2 = ld2(ct1 + r);
+            s0 = fma(a2.x, y2.x, s0); s0 = fma(a2.y, y2.y, s0);
+            s1 = fma(b2.x, y2.x, s1); s1 = fma(b2.y, y2.y, s1);
         }
         nu0 = -s0;
         nu1 = var1 ? -s1 : 0.0;
     }
     wcqp::wave_lds_fence();
 
+    WCQP_STAMP(7);
     // ---------------- phase 6: joint-velocity bounds (qpOASES form), in the scaled variable -----------------
     int st_code = ok ? WCQP_STATUS_SOLVED : WCQP_STATUS_NUMERIC;
     int it = 0;
@@ -385,14 +418,12 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const unsigned long long need_m = __ballot(need);
     if (((need_m >> (16 * grp)) & 0xffffull) != 0ull && st_code == WCQP_STATUS_SOLVED) {
         // Goldfarb-Idnani dual active set on columns of P = I - C' M^-1 C (see ik3.hip phase 5 for the scheme;
-        // the differences: a column tau_p costs one published column of C, a 12 x 12 product by rows and a
+        // the differences: a column tau_p costs a broadcast read of column p of C^T, a 12 x 12 product by rows and a
         // column-local dot product; entries of tau_p at other variables travel by ds_bpermute).
-        double* cpv = S + OFF_CPV;
         double* ypv = S + OFF_YPV;
-        double* tpb = S + OFF_TPB;
         double* rvec = S + OFF_RV;
         double* cvec = S + OFF_CV;
-        double* Rinv = S + OFF_RINV;
+        double* rowb = S + OFF_ROWB;
         int* Wi = reinterpret_cast<int*>(S + OFF_WI);
         const int rowbase = lane & 48;
         bool pending = false;
@@ -420,14 +451,14 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         auto at_var = [&](double v0, double v1, int w) -> double {
             return lane_gather(w >= 16 ? v1 : v0, (rowbase + (w & 15)) << 2);
         };
-        // P v for a vector given by its entries on the own variables: v - C' M^-1 (C v); `single`: v = e_p (the
-        // owner publishes its column, no reduction)
+        // P v for a vector given by its entries on the own variables: v - C' M^-1 (C v)
         auto apply_P = [&](double v0, double v1, double& z0, double& z1) {
             double t = 0.0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const double cvr = row_sum(fma(v0, c0[r], v1 * c1[r]));
-                t = fma(Hr[r], cvr, t);                   // -(M^-1 C v)_j on lanes j < 12
+            for (int r = 0; r < NR; r += 2) {
+                const double2 a2 = ld2(ct0 + r), b2 = ld2(ct1 + r);
+                t = fma(Hr[r], row_sum(fma(v0, a2.x, v1 * b2.x)), t);          // -(M^-1 C v)_j on lanes j < 12
+                t = fma(Hr[r + 1], row_sum(fma(v0, a2.y, v1 * b2.y)), t);
             }
             wcqp::wave_lds_fence();
             ypv[j] = j < NR ? t : 0.0;
@@ -436,12 +467,14 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
             for (int r = 0; r < NR; r += 2) {
                 const double2 y2 = ld2(ypv + r);
-                z0 = fma(c0[r], y2.x, z0); z0 = fma(c0[r + 1], y2.y, z0);
-                z1 = fma(c1[r], y2.x, z1); z1 = fma(c1[r + 1], y2.y, z1);
+                const double2 a2 = ld2(ct0 + r), b2 = ld2(ct1 + r);
+                z0 = fma(a2.x, y2.x, z0); z0 = fma(a2.y, y2.y, z0);
+                z1 = fma(b2.x, y2.x, z1); z1 = fma(b2.y, y2.y, z1);
             }
         };
-        // makes the bound of `key` the pending one: p, sig, s, signed column tau_p, P[p][p]
-        auto enter = [&](unsigned key, bool general) {
+        // makes the bound of `key` the pending one: p, sig, s, signed column tau_p, P[p][p]; `replicated`: also
+        // tau_p at the variables of the replicated working set
+        auto enter = [&](unsigned key, bool replicated) {
             ++it;
             p = 31 - (int)(key & 31u);
             const bool sl1 = p >= 16;
@@ -451,16 +484,12 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             const double sv_p = lane_gather(sviol, src);
             s = fabs(sv_p);
             sig = sv_p >= 0.0 ? 1.0 : -1.0;
-            wcqp::wave_lds_fence();
-            if (j == (p & 15)) {
-#pragma unroll
-                for (int r = 0; r < NR; r += 2) st2(cpv + r, sl1 ? c1[r] : c0[r], sl1 ? c1[r + 1] : c0[r + 1]);
-            }
+            const double* colp = S + OFF_CT + p * LDC;                   // broadcast read: p is uniform in the row
             wcqp::wave_lds_fence();
             double t = 0.0;
 #pragma unroll
             for (int r = 0; r < NR; r += 2) {
-                const double2 c2 = ld2(cpv + r);
+                const double2 c2 = ld2(colp + r);
                 t = fma(Hr[r], c2.x, t); t = fma(Hr[r + 1], c2.y, t);
             }
             ypv[j] = j < NR ? t : 0.0;                                   // -(M^-1 c_p)_j
@@ -469,22 +498,24 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
             for (int r = 0; r < NR; r += 2) {
                 const double2 y2 = ld2(ypv + r);
-                u0 = fma(c0[r], y2.x, u0); u0 = fma(c0[r + 1], y2.y, u0);
-                u1 = fma(c1[r], y2.x, u1); u1 = fma(c1[r + 1], y2.y, u1);
+                const double2 a2 = ld2(ct0 + r), b2 = ld2(ct1 + r);
+                u0 = fma(a2.x, y2.x, u0); u0 = fma(a2.y, y2.y, u0);
+                u1 = fma(b2.x, y2.x, u1); u1 = fma(b2.y, y2.y, u1);
             }
             u1 = var1 ? u1 : 0.0;
             ppp = lane_gather(sl1 ? u1 : u0, src);                       // P[p][p] > 0
+            if (replicated) {
 #pragma unroll
-            for (int a = 0; a < KS; ++a) tvS[a] = at_var(u0, u1, wS[a]);   // tau_p at the replicated working set
+                for (int a = 0; a < KS; ++a) tvS[a] = at_var(u0, u1, wS[a]);
+            }
             tp0 = sig * u0; tp1 = sig * u1;
-            if (general) { tpb[j] = tp0; tpb[col1] = tp1; }
             mu_p = 0.0;
             pending = true;
         };
         // First bound, empty working set, straight-line: full step along tau_p, the bound takes slot 0.
         {
             const unsigned key = most_violated();          // != 0: that is what `need` said
-            enter(key, false);
+            enter(key, true);
             if (ppp > 0.0) {
                 const double inz = wcqp::fast_rcp(ppp);
                 const double t = s * inz;
@@ -509,7 +540,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const unsigned key = most_violated();
                 if (key == 0u) { done = true; small = false; break; }
                 if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; small = false; break; }
-                enter(key, false);
+                enter(key, true);
             }
             double c[KS], r[KS];
 #pragma unroll
@@ -594,47 +625,44 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             }
         }
         if (!done) {
-            // ---- working sets of more than KS bounds: slot a is owned by lane a, row a of the explicit inverse of
-            // the active-bound system sits in LDS; the primal step is P applied to the sparse vector
-            // sig e_p - sum_a r_a sigma_a e_{w_a} (no stored columns: registers are what this kernel saves)
+            // ---- working sets of more than KS bounds: slot a is owned by lane a, which keeps ROW a of the explicit
+            // inverse of the active-bound system in registers (static indices only; the row of a leaving slot goes
+            // round through LDS); the primal step is P applied to the sparse vector
+            // sig e_p - sum_a r_a sigma_a e_{w_a}, so no column of an active bound is stored anywhere.
             bool s_live = false;
             int s_var = 0;
             double s_sg = 0.0, s_mu = 0.0;
             int slot0 = 0, slot1 = 0;                   // slot of the own variables while they are in the working set
-            double* myR = Rinv + (j < KMAX ? j : 0) * LDR;
-            {
-                double myrow[KS];
+            double myR[KMAX];
 #pragma unroll
-                for (int b = 0; b < KS; ++b) {
-                    myrow[b] = 0.0;
+            for (int b = 0; b < KMAX; ++b) myR[b] = 0.0;
 #pragma unroll
-                    for (int a = 0; a < KS; ++a) myrow[b] = (a == j) ? (b >= a ? Rs[a][b] : Rs[b][a]) : myrow[b];
+            for (int a = 0; a < KS; ++a) {
+                if (a == j) {
+                    s_live = sgS[a] != 0.0; s_var = wS[a]; s_sg = sgS[a]; s_mu = muS[a]; Wi[a] = wS[a];
+#pragma unroll
+                    for (int b = 0; b < KS; ++b) myR[b] = b >= a ? Rs[a][b] : Rs[b][a];
                 }
-                wcqp::wave_lds_fence();
-#pragma unroll
-                for (int a = 0; a < KS; ++a) {
-                    if (a == j) { s_live = sgS[a] != 0.0; s_var = wS[a]; s_sg = sgS[a]; s_mu = muS[a]; Wi[a] = wS[a]; }
-                    if (sgS[a] != 0.0 && wS[a] == j) slot0 = a;
-                    if (sgS[a] != 0.0 && wS[a] == col1) slot1 = a;
-                }
-                if (j < KMAX) {
-#pragma unroll
-                    for (int b = 0; b < KMAX; ++b) myR[b] = (b < KS) ? myrow[b < KS ? b : 0] : 0.0;
-                }
-                if (pending) { tpb[j] = tp0; tpb[col1] = tp1; }
-                wcqp::wave_lds_fence();
+                if (sgS[a] != 0.0 && wS[a] == j) slot0 = a;
+                if (sgS[a] != 0.0 && wS[a] == col1) slot1 = a;
             }
+            wcqp::wave_lds_fence();
 #pragma unroll 1
             for (int pass = 0; pass < 1024 && !done; ++pass) {
                 if (!pending) {
                     const unsigned key = most_violated();
                     if (key == 0u) { done = true; }
                     else if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; }
-                    else { enter(key, true); wcqp::wave_lds_fence(); }
+                    else enter(key, false);
                 }
                 if (!done) {
-                    // dual step r = Rinv c,  c_a = sigma_a tau_p[w_a]
-                    cvec[j] = s_live ? s_sg * tpb[s_var] : 0.0;
+                    // dual step r = Rinv c,  c_a = sigma_a tau_p[w_a]  (tau_p at the slot's variable: both slots of
+                    // its owner lane travel, the reader picks)
+                    const int wsrc = (rowbase + (s_var & 15)) << 2;
+                    const double tw0 = lane_gather(tp0, wsrc), tw1 = lane_gather(tp1, wsrc);    // every lane takes part in both
+                    const double tw = s_var >= 16 ? tw1 : tw0;
+                    wcqp::wave_lds_fence();
+                    cvec[j] = s_live ? s_sg * tw : 0.0;
                     wcqp::wave_lds_fence();
                     double r_a = 0.0;
 #pragma unroll
@@ -666,7 +694,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                         mu_p += t;
                         s -= t * nzv;
                         if (t2 <= t1) {
-                            // full step: p enters the first free slot; Rinv <- bordered inverse
+                            // full step: p enters the first free slot n; Rinv <- bordered inverse
                             const unsigned fm = (unsigned)((__ballot(j < KMAX && !s_live) >> (16 * grp)) & 0xffffull);
                             const int n = fm ? __ffs(fm) - 1 : 0;
                             const double ra_inz = r_a * inz;         // 0 on lanes without a live slot
@@ -676,31 +704,34 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                                 const double2 r2 = ld2(rvec + b);
                                 const double u0 = me ? -r2.x * inz : fma(ra_inz, r2.x, myR[b]);
                                 const double u1 = me ? -r2.y * inz : fma(ra_inz, r2.y, myR[b + 1]);
-                                if (j < KMAX) { myR[b] = u0; myR[b + 1] = u1; }
+                                myR[b] = (b == n) ? (me ? inz : -ra_inz) : u0;
+                                myR[b + 1] = (b + 1 == n) ? (me ? inz : -ra_inz) : u1;
                             }
-                            wcqp::wave_lds_fence();
-                            if (j < KMAX) myR[n] = me ? inz : -ra_inz;
                             if (me) { s_live = true; s_var = p; s_sg = sig; s_mu = mu_p; Wi[n] = p; }
                             if (p == j) { in_w0 = true; sig0 = sig; slot0 = n; }
                             if (p == col1) { in_w1 = true; sig1 = sig; slot1 = n; }
                             ++nW;
                             pending = false;
                         } else {
-                            // partial step: the blocking constraint leaves the working set; Rinv <- downdated inverse
+                            // partial step: the blocking slot jd leaves the working set; Rinv <- downdated inverse
                             const unsigned dm = (unsigned)((__ballot(ratio == t1) >> (16 * grp)) & 0xffffull);
                             const int jd = dm ? __ffs(dm) - 1 : 0;
-                            const int wdrop = Wi[jd];
-                            const double* dR = Rinv + jd * LDR;
-                            const double djj = dR[jd];
-                            const double f = (s_live && j != jd) ? dR[j < KMAX ? j : 0] * wcqp::fast_rcp(djj) : 0.0;      // Rinv is symmetric
-                            double u[KMAX];
-#pragma unroll
-                            for (int b = 0; b < KMAX; ++b) u[b] = (j == jd) ? 0.0 : fma(-f, dR[b], myR[b]);
                             wcqp::wave_lds_fence();
-                            if (j < KMAX) {
+                            if (j == jd) {
 #pragma unroll
-                                for (int b = 0; b < KMAX; ++b) myR[b] = u[b];
-                                myR[jd] = 0.0;
+                                for (int b = 0; b < KMAX; b += 2) st2(rowb + b, myR[b], myR[b + 1]);
+                            }
+                            wcqp::wave_lds_fence();
+                            const int wdrop = Wi[jd];
+                            double myjd = 0.0;                        // Rinv[j][jd] (Rinv is symmetric: = row jd, entry j)
+                            const double djj = rowb[jd];
+                            myjd = rowb[j < KMAX ? j : 0];
+                            const double f = (s_live && j != jd) ? myjd * wcqp::fast_rcp(djj) : 0.0;
+#pragma unroll
+                            for (int b = 0; b < KMAX; b += 2) {
+                                const double2 d2 = ld2(rowb + b);
+                                myR[b] = (j == jd || b == jd) ? 0.0 : fma(-f, d2.x, myR[b]);
+                                myR[b + 1] = (j == jd || b + 1 == jd) ? 0.0 : fma(-f, d2.y, myR[b + 1]);
                             }
                             if (j == jd) { s_live = false; s_mu = 0.0; }
                             if (wdrop == j) { in_w0 = false; sig0 = 0.0; }
@@ -723,6 +754,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         }
     }
 
+    WCQP_STAMP(8);
     // ---------------- outputs (back in the unscaled variable) ----------------------------------------------
     double dq0 = nu0 * sd0, dq1 = nu1 * sd1;
     if (st_code == WCQP_STATUS_SOLVED && in_w0) dq0 = sig0 > 0.0 ? prm->vhi[v0i] : prm->vlo[v0i];
@@ -746,6 +778,10 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             if (iters_out) iters_out[inst] = it;
         }
     }
+#ifdef WCQP_IK_STAMPS
+    WCQP_STAMP(9);
+    return;
+#endif
     if constexpr (TICK) {
         const bool ik_ok = st_code == WCQP_STATUS_SOLVED;
         if (live) {
