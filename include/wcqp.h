@@ -300,9 +300,9 @@ int wcqp_kin_jacobians_host(wcqp_kin_t h, int32_t batch, const double* base, con
  *         velocity into the IK pose block (WalkingModule.cpp:686-695); synthetic LIPM plant
  *   IK    joint velocities
  *   post  q <- Integrator(dq) (WalkingModule.cpp:741-744), contact pair of the next tick, tick += 1
- * With the default IK kernel the glue and post steps run inside the IK kernel (two launches per
- * tick: MPC, IK); an explicit 32-lane / sweep IK algorithm or the CoM-as-cost variant keeps them as
- * stand-alone kernels (four launches).  `use_graph` replays hipGraphs of 8 ticks each (captured
+ * With the default IK kernel (base elimination) the MPC, the glue, the IK and the post step run in ONE
+ * launch per tick; the general 16-lane kernel (algorithm 4) takes two (MPC, IK), an explicit 32-lane / sweep IK
+ * algorithm or the CoM-as-cost variant four (stand-alone glue / post kernels).  `use_graph` replays hipGraphs of 8 ticks each (captured
  * ONCE: the tick index lives in device memory), remaining ticks go as plain launches.
  * ===================================================================================== */
 typedef struct wcqp_tick_params {
@@ -344,7 +344,9 @@ typedef struct wcqp_tick_s* wcqp_tick_t;
 int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out);
 int wcqp_tick_destroy(wcqp_tick_t h);
 int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in);                 /* also rewinds to tick 0 */
-int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream); /* enqueue only; use_graph: hipGraph replays of 8 ticks each, remainder as plain launches */
+/* enqueue only; use_graph: hipGraph replays of 8 ticks each, remainder as plain launches.  WCQP_E_INVALID when the ticks
+ * enqueued since the last upload + n_ticks would exceed max_ticks (the trajectories end there). */
+int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream);
 int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out);             /* synchronises     */
 
 #ifdef __cplusplus

@@ -27,10 +27,11 @@ def test_contact_schedule_and_reference_are_consistent(wca):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ik_algorithm", [0, 3], ids=["fused_2_launches", "4_launches"])
+@pytest.mark.parametrize("ik_algorithm", [0, 4, 3], ids=["fused_1_launch", "2_launches", "4_launches"])
 def test_tick_pipeline_matches_cpu_restatement(wca, qs, ik_algorithm):
-    """Default IK algorithm: glue and post steps run inside the 16-lane IK kernel (2 launches per tick);
-    an explicit 32-lane algorithm keeps the stand-alone glue / post kernels (4 launches per tick)."""
+    """Default IK algorithm (base elimination): MPC, glue, IK and post step run in ONE launch per tick; the general
+    16-lane kernel keeps the MPC launch (2 per tick); an explicit 32-lane algorithm keeps the stand-alone glue /
+    post kernels as well (4 per tick)."""
     from oracle import tick_spec as ts
     B, T = 24, 150            # > one contact change per instance (double support lasts 110 ticks)
     p = ts.TickParams()
@@ -74,3 +75,31 @@ def test_tick_pipeline_long_run_is_stable_and_shard_invariant(wca):
     halves = [run(wca.synth.synth_tick_batch(B // 2, T, first=f), f, B // 2) for f in (0, B // 2)]
     assert np.array_equal(np.concatenate([h["q_des"] for h in halves]), full["q_des"])
     assert np.array_equal(np.concatenate([h["dcm"] for h in halves]), full["dcm"])
+
+
+@pytest.mark.gpu
+def test_tick_run_refuses_to_run_past_the_trajectories(wca):
+    """The per-instance trajectories hold max_ticks + N + 1 stages: enqueueing more ticks than that (in one call or
+    over several) must be refused, not read the neighbour's trajectory; odd tick counts exercise the
+    phase parity of the two-copy tick index with and without graph replays."""
+    B, T = 8, 30
+    d = wca.synth.synth_tick_batch(B, T)
+    ik = lambda: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.5)
+    ref = wca.TickPipeline(B, T, wca.MpcSolver(), ik(), log_ticks=T)
+    ref.upload(d); ref.run(T, use_graph=False)
+    want = ref.download()
+    pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik(), log_ticks=T)
+    pipe.upload(d)
+    with pytest.raises(wca.WcqpError):
+        pipe.run(T + 1, use_graph=False)
+    pipe.run(3, use_graph=True)          # plain (fewer than a graph's 8 ticks), leaves an odd tick index
+    pipe.run(19, use_graph=True)         # one plain tick to an even index, two graph replays, two plain ticks
+    pipe.run(8, use_graph=False)
+    with pytest.raises(wca.WcqpError):
+        pipe.run(1, use_graph=True)
+    got = pipe.download()
+    assert got["tick"] == T
+    assert np.array_equal(got["u0_log"], want["u0_log"]) and np.array_equal(got["dq_log"], want["dq_log"])
+    pipe.upload(d)                       # upload rewinds
+    pipe.run(T, use_graph=True)
+    assert np.array_equal(pipe.download()["dq_log"], want["dq_log"])

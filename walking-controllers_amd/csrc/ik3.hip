@@ -127,7 +127,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const int col1 = j + 16;
 
     int tick_now = 0;
-    if constexpr (TICK) tick_now = *td.tick_latched;
+    if constexpr (TICK) tick_now = td.tick2[td.phase];
 
     WCQP_STAMP(0);
     // ---------------- phase 0: loads ------------------------------------------------------------
@@ -158,7 +158,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const int i_ = (int)inst;
                 const int mst = td.mpc_status[i_];
                 const bool mpc_ok = mst == WCQP_STATUS_SOLVED || mst == WCQP_STATUS_OUTSIDE_HULL;
-                if (j < 2) wcqp_tick::tick_glue_axis(td, i_, tick_now, j, mpc_ok, g_com, g_pstar, g_vel);
+                if (j < 2) wcqp_tick::tick_glue_axis(td, i_, tick_now, j, mpc_ok, td.u0[2 * i_ + j], g_com, g_pstar, g_vel);
                 if (j < 6) wcqp_tick::tick_glue_twist(td, i_, td.sel[i_], j, g_twl, g_twr);
                 if (j == 0 && !mpc_ok) td.mpc_fail[i_] += 1;
             }
@@ -934,9 +934,8 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             if (var1) wcqp_tick::tick_post_joint(td, i_, tick_now, j + 10, ik_ok, nu1);
             if (j == 0) wcqp_tick::tick_post_instance(td, i_, tick_now, ik_ok);
         }
-        // advanceReferenceSignals (WalkingModule.cpp:816): every kernel after the MPC reads the tick index
-        // from the copy the MPC kernel made, so `tick` itself may advance as soon as this kernel runs
-        if (blockIdx.x == 0 && lane == 0) *td.tick = tick_now + 1;
+        // advanceReferenceSignals (WalkingModule.cpp:816): the next tick reads the other copy of the tick index
+        if (blockIdx.x == 0 && lane == 0) td.tick2[1 - td.phase] = tick_now + 1;
     }
     if (ferr_out) {
         // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401): every lane multiplies its two

@@ -48,7 +48,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int NR = 12;                // rows of C = [Nt (3); A_right (6); A_com (3)]
 constexpr int NROWS_IN = 18;          // J_left 6, J_right 6, J_com 3, J_neck 3
 constexpr int KMAX = kDof - 9;        // 14: largest working set (n - m_eq)
-constexpr int LDR = KMAX | 1;         // 15
 constexpr int LDC = 14;               // leading dimension of C^T (k-major) and of the Gram tile: b128 row accesses of 16
                                       // lanes land on 16 distinct groups of 4 banks (28 j mod 64)
 
@@ -132,7 +131,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const int col1 = j + 16;
 
     int tick_now = 0;
-    if constexpr (TICK) tick_now = *td.tick_latched;
+    if constexpr (TICK) tick_now = td.tick2[td.phase];
 
     WCQP_STAMP(0);
     // ---------------- phase 0: loads ------------------------------------------------------------
@@ -145,6 +144,18 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const int fast_ok = prm->fast_ok;
     double a0[NROWS_IN], a1[NROWS_IN];     // columns of [J_left; J_right; J_com; J_neck]
     double q0, q1;
+    // tick pipeline: this tick's DCM-MPC on the same 16 lanes (what mpc_condensed_kernel does as a launch of its
+    // own elsewhere): window [t, t+N] of the instance's DCM trajectory, hull rows of the current contact pair,
+    // x0 = measured DCM, u_prev = previous output.  Its result stays in registers for the glue below.
+    double mpc_ux = 0.0, mpc_uy = 0.0;
+    int mpc_st = WCQP_STATUS_SOLVED;
+    if constexpr (TICK) {
+        const double2* rp = reinterpret_cast<const double2*>(td.ref_traj) + inst * td.traj_len + tick_now;
+        const long hset = inst * td.hull_sets + (td.hull_sets > 1 ? td.sel[inst] : 0);
+        unsigned mact; double mmar;
+        wcqp_mpc::mpc_row_solve(td.mpc, j, inst, td.dcm, rp, td.horizon + 1, td.u_prev, td.hull_tab_A, td.hull_tab_b, td.hull_tab_nc, hset,
+                                reinterpret_cast<double (*)[4]>(S + OFF_COL), mpc_ux, mpc_uy, mpc_st, mact, mmar);
+    }
     {
         // the state block first: vmcnt retires in order, and the rhs phase only needs the state, so the 36
         // Jacobian loads stay in flight underneath it
@@ -159,9 +170,8 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         if constexpr (TICK) {
             if (live) {
                 const int i_ = (int)inst;
-                const int mst = td.mpc_status[i_];
-                const bool mpc_ok = mst == WCQP_STATUS_SOLVED || mst == WCQP_STATUS_OUTSIDE_HULL;
-                if (j < 2) wcqp_tick::tick_glue_axis(td, i_, tick_now, j, mpc_ok, g_com, g_pstar, g_vel);
+                const bool mpc_ok = mpc_st == WCQP_STATUS_SOLVED || mpc_st == WCQP_STATUS_OUTSIDE_HULL;
+                if (j < 2) wcqp_tick::tick_glue_axis(td, i_, tick_now, j, mpc_ok, j == 0 ? mpc_ux : mpc_uy, g_com, g_pstar, g_vel);
                 if (j < 6) wcqp_tick::tick_glue_twist(td, i_, td.sel[i_], j, g_twl, g_twr);
                 if (j == 0 && !mpc_ok) td.mpc_fail[i_] += 1;
             }
@@ -790,9 +800,8 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             if (var1) wcqp_tick::tick_post_joint(td, i_, tick_now, col1, ik_ok, dq1);
             if (j == 0) wcqp_tick::tick_post_instance(td, i_, tick_now, ik_ok);
         }
-        // advanceReferenceSignals (WalkingModule.cpp:816): every kernel after the MPC reads the tick index
-        // from the copy the MPC kernel made, so `tick` itself may advance as soon as this kernel runs
-        if (blockIdx.x == 0 && lane == 0) *td.tick = tick_now + 1;
+        // advanceReferenceSignals (WalkingModule.cpp:816): the next tick reads the other copy of the tick index
+        if (blockIdx.x == 0 && lane == 0) td.tick2[1 - td.phase] = tick_now + 1;
     }
     if (ferr_out) {
         // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401) with nu = (v_base, dq) and

@@ -20,42 +20,17 @@
 #include <limits>
 #include <new>
 #include "wcqp_internal.h"
+#include "mpc_device.h"
 
 namespace {
 
-constexpr int kLanesPerInstance = 16;   // one DPP row per instance, 4 instances per wave
-constexpr int kInstPerWave = 64 / kLanesPerInstance;
+using namespace wcqp_mpc;
 constexpr int kBlock = 64;              // one wavefront per workgroup
-
-// candidate 0: no row; 1..8: single row e = id-1; 9..36: row pairs (e < f)
-__device__ const unsigned char kPairE[28] = {0,0,0,0,0,0,0, 1,1,1,1,1,1, 2,2,2,2,2, 3,3,3,3, 4,4,4, 5,5, 6};
-__device__ const unsigned char kPairF[28] = {1,2,3,4,5,6,7, 2,3,4,5,6,7, 3,4,5,6,7, 4,5,6,7, 5,6,7, 6,7, 7};
-constexpr int kNumCand = 1 + 8 + 28;
-
-// One DPP move of both halves of a double inside a row of 16 lanes (= one instance here).
-template <int CTRL>
-__device__ __forceinline__ double row_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ int row_move(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-// the four butterfly partners inside a row: xor 1, xor 2 (quad permutes), then half-mirror and
-// mirror, which pair quads / octets whose lanes already agree
-#define WCQP_ROW_STEPS(X) X(0xB1) X(0x4E) X(0x141) X(0x140)
-
-struct MpcDeviceConsts {
-    const double* Gr;     // (N+1) x 2 x 2
-    double Gx[4], Gu[4], S0[4];
-    double feas_tol, hull_tol;
-    int N;
-};
 
 __global__ __launch_bounds__(kBlock)
 void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
                           const double* __restrict__ x0, const double* __restrict__ ref, int ref_len,
-                          int ref_stride, const int* __restrict__ ref_start, int* __restrict__ ref_start_copy,
+                          int ref_stride, const int* __restrict__ ref_start,
                           const double* __restrict__ u_prev,
                           const double* __restrict__ hull_A, const double* __restrict__ hull_b,
                           const int* __restrict__ hull_nc, int hull_sets, const int* __restrict__ hull_sel,
@@ -71,139 +46,21 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
     const bool live = inst_raw < batch;
     const long inst = live ? inst_raw : (long)batch - 1;   // dead slots shadow the last instance, never store
 
-    // ---- u0_unc = sum_i Gr_i r_i + Gx x0 + Gu u_prev ---------------------------------
     // the reference window of an instance starts `*ref_start` stages into its trajectory (the
     // deque of the reference advanced by that many ticks); instances are `ref_stride` stages apart
     const int start = ref_start ? *ref_start : 0;
-    // tick pipeline: the next kernel of the tick reads the tick index from this copy, so that it may
-    // advance `*ref_start` itself while some of its workgroups have not started yet
-    if (ref_start_copy && blockIdx.x == 0 && lane == 0) *ref_start_copy = start;
     const double2* rp = reinterpret_cast<const double2*>(ref) + inst * ref_stride + start;
-    const double2* gp = reinterpret_cast<const double2*>(c.Gr);
-    double ux = 0.0, uy = 0.0;
-    // 64 stages per pass: the four reference loads of a lane (stages t, t+16, t+32, t+48) are
-    // issued back to back before any is consumed, so one HBM round trip covers the whole window
-    // of the N = 50 benchmark instead of four serialized ones
-    for (int base = 0; base <= c.N; base += 4 * kLanesPerInstance) {
-        double2 r[4], g0[4], g1[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + t + k * kLanesPerInstance;
-            const int ic = i <= c.N ? i : c.N;                // clamped: stays in bounds, weight zeroed below
-            const int ir = ic < ref_len ? ic : ref_len - 1;   // MPCSolver.cpp:200-214 (constant tail)
-            r[k] = rp[ir];
-            g0[k] = gp[2 * ic]; g1[k] = gp[2 * ic + 1];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double m = (base + t + k * kLanesPerInstance) <= c.N ? 1.0 : 0.0;
-            ux = fma(m * g0[k].x, r[k].x, fma(m * g0[k].y, r[k].y, ux));
-            uy = fma(m * g1[k].x, r[k].x, fma(m * g1[k].y, r[k].y, uy));
-        }
-    }
-    if (t == 0) {
-        const double2 xs = reinterpret_cast<const double2*>(x0)[inst];
-        const double2 up = reinterpret_cast<const double2*>(u_prev)[inst];
-        ux += c.Gx[0] * xs.x + c.Gx[1] * xs.y + c.Gu[0] * up.x + c.Gu[1] * up.y;
-        uy += c.Gx[2] * xs.x + c.Gx[3] * xs.y + c.Gu[2] * up.x + c.Gu[3] * up.y;
-    }
-    // hull rows -> LDS (lanes 0..7 of the instance own one row each)
     // an instance may carry several precomputed row sets (one per contact pair); `hull_sel` picks
     // the live one, so a contact change costs no copy (tick pipeline)
     const long hset = inst * hull_sets + (hull_sel ? hull_sel[inst] : 0);
-    int nc = hull_nc[hset];
-    nc = nc < 0 ? 0 : (nc > WCQP_HULL_ROWS ? WCQP_HULL_ROWS : nc);
-    double rax = 0.0, ray = 0.0, rb = 0.0, rn = 0.0;    // this lane's own hull row (lanes 0..7)
-    if (t < WCQP_HULL_ROWS) {
-        const double2 a = reinterpret_cast<const double2*>(hull_A)[hset * WCQP_HULL_ROWS + t];
-        rb = hull_b[hset * WCQP_HULL_ROWS + t];
-        rax = a.x; ray = a.y; rn = sqrt(a.x * a.x + a.y * a.y);
-        s_hull[sub][t][0] = rax; s_hull[sub][t][1] = ray; s_hull[sub][t][2] = rb; s_hull[sub][t][3] = rn;
-    }
-    // butterfly over the row (DPP, no LDS-pipe round trips): every lane ends with the same sum
-#define WCQP_SUM_STEP(C) ux += row_move<C>(ux); uy += row_move<C>(uy);
-    WCQP_ROW_STEPS(WCQP_SUM_STEP)
-#undef WCQP_SUM_STEP
-    wcqp::wave_lds_fence();
-
-    // ---- projection onto the polygon in the Sigma0^-1 metric --------------------------
-    const double s00 = c.S0[0], s01 = c.S0[1], s10 = c.S0[2], s11 = c.S0[3];
-    double best_cost = std::numeric_limits<double>::infinity();
-    double best_x = ux, best_y = uy;
-    unsigned best_mask = 0;
-    int best_id = kNumCand;
-    // Early out (wave-uniform): when the unconstrained optimum of every instance of this wave
-    // already satisfies its hull rows, candidate 0 wins by construction (cost 0, lowest id) and the
-    // 37-candidate enumeration is skipped.  Same feasibility test as the enumeration applies to
-    // candidate 0, so the result is identical either way.
-    const bool row_violated = t < nc && (rax * ux + ray * uy - rb) > c.feas_tol;
-    if (__ballot(row_violated) == 0ull) {
-        best_cost = 0.0; best_id = 0;
-    } else
-    for (int id = t; id < kNumCand; id += kLanesPerInstance) {
-        int e = -1, f = -1;
-        if (id >= 1 && id <= 8) e = id - 1;
-        else if (id > 8) { e = kPairE[id - 9]; f = kPairF[id - 9]; }
-        if (e >= nc || f >= nc) continue;
-        double px = ux, py = uy, cost = 0.0;
-        unsigned mask = 0;
-        bool ok = true;
-        if (e >= 0) {
-            const double aex = s_hull[sub][e][0], aey = s_hull[sub][e][1];
-            const double sex = s00 * aex + s01 * aey, sey = s10 * aex + s11 * aey;   // Sigma0 a_e
-            const double ree = aex * sex + aey * sey;
-            const double re  = aex * ux + aey * uy - s_hull[sub][e][2];
-            mask = 1u << e;
-            if (f < 0) {
-                ok = ree > 0.0;
-                const double mu = ok ? re * wcqp::fast_rcp(ree) : 0.0;
-                px = ux - sex * mu; py = uy - sey * mu;
-                cost = mu * re;
-            } else {
-                const double afx = s_hull[sub][f][0], afy = s_hull[sub][f][1];
-                const double sfx = s00 * afx + s01 * afy, sfy = s10 * afx + s11 * afy;
-                const double rff = afx * sfx + afy * sfy;
-                const double ref_ = aex * sfx + aey * sfy;
-                const double rf  = afx * ux + afy * uy - s_hull[sub][f][2];
-                const double det = ree * rff - ref_ * ref_;
-                ok = det > 1e-12 * ree * rff;                 // parallel rows have no vertex
-                const double idet = ok ? wcqp::fast_rcp(det) : 0.0;
-                const double mue = (rff * re - ref_ * rf) * idet;
-                const double muf = (ree * rf - ref_ * re) * idet;
-                px = ux - sex * mue - sfx * muf; py = uy - sey * mue - sfy * muf;
-                cost = mue * re + muf * rf;
-                mask |= 1u << f;
-            }
-        }
-        for (int k = 0; k < nc; ++k) {
-            const double res = s_hull[sub][k][0] * px + s_hull[sub][k][1] * py - s_hull[sub][k][2];
-            ok = ok && (k == e || k == f || res <= c.feas_tol);
-        }
-        if (ok && (cost < best_cost || (cost == best_cost && id < best_id))) {
-            best_cost = cost; best_x = px; best_y = py; best_mask = mask; best_id = id;
-        }
-    }
-#define WCQP_MIN_STEP(C) {                                                              \
-        const double oc = row_move<C>(best_cost), ox = row_move<C>(best_x), oy = row_move<C>(best_y); \
-        const int om = row_move<C>((int)best_mask), oi = row_move<C>(best_id);                 \
-        if (oc < best_cost || (oc == best_cost && oi < best_id)) {                             \
-            best_cost = oc; best_x = ox; best_y = oy; best_mask = (unsigned)om; best_id = oi;  \
-        } }
-    WCQP_ROW_STEPS(WCQP_MIN_STEP)
-#undef WCQP_MIN_STEP
-    // signed distance to the hull boundary (computeMargin semantics): every row lane evaluates its
-    // own row, row-min by DPP
-    double margin = (t < nc && rn > 0.0) ? (rb - rax * best_x - ray * best_y) / rn : std::numeric_limits<double>::infinity();
-#define WCQP_MARGIN_STEP(C) margin = fmin(margin, row_move<C>(margin));
-    WCQP_ROW_STEPS(WCQP_MARGIN_STEP)
-#undef WCQP_MARGIN_STEP
+    double ux, uy, margin;
+    int st;
+    unsigned mask;
+    mpc_row_solve(c, t, inst, x0, rp, ref_len, u_prev, hull_A, hull_b, hull_nc, hset, s_hull[sub], ux, uy, st, mask, margin);
     if (t == 0 && live) {
-        int st = best_id < kNumCand ? WCQP_STATUS_SOLVED : WCQP_STATUS_INFEASIBLE;
-        // WalkingController::solve: computeMargin(u0) < -tolerance => failure (cpp:513-517)
-        if (st == WCQP_STATUS_SOLVED && margin < -c.hull_tol) st = WCQP_STATUS_OUTSIDE_HULL;
-        reinterpret_cast<double2*>(u0_out)[inst] = make_double2(best_x, best_y);
+        reinterpret_cast<double2*>(u0_out)[inst] = make_double2(ux, uy);
         status_out[inst] = st;
-        if (active_out) active_out[inst] = best_mask;
+        if (active_out) active_out[inst] = mask;
         if (margin_out) margin_out[inst] = margin;
     }
 }
@@ -333,7 +190,7 @@ int ensure_device(wcqp_mpc_s* h) {
 namespace wcqp {
 
 int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, int ref_len, int ref_stride,
-                const int* ref_start_dev, int* ref_start_copy_dev, const double* u_prev,
+                const int* ref_start_dev, const double* u_prev,
                 const double* hull_A, const double* hull_b, const int* hull_nc, int hull_sets, const int* hull_sel,
                 double* u0, int* status, unsigned* active, double* margin, hipStream_t stream) {
     if (!h || batch < 0 || ref_len < 1 || ref_stride < ref_len || hull_sets < 1) return WCQP_E_INVALID;
@@ -342,22 +199,25 @@ int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, in
     const int rc = ensure_device(h);
     if (rc != WCQP_OK) return rc;
     MpcDeviceConsts c;
-    c.Gr = h->d_Gr;
-    std::memcpy(c.Gx, h->Gx, sizeof(c.Gx));
-    std::memcpy(c.Gu, h->Gu, sizeof(c.Gu));
-    std::memcpy(c.S0, h->S0, sizeof(c.S0));
-    c.feas_tol = h->p.feas_tol;
-    c.hull_tol = h->p.convex_hull_tolerance;
-    c.N = h->N;
+    mpc_device_consts(h, &c);
     const unsigned grid = (unsigned)((batch + kInstPerWave - 1) / kInstPerWave);
     hipLaunchKernelGGL(mpc_condensed_kernel, dim3(grid), dim3(kBlock), 0, stream,
-                       c, batch, x0, ref, ref_len, ref_stride, ref_start_dev, ref_start_copy_dev, u_prev, hull_A, hull_b, hull_nc, hull_sets, hull_sel,
+                       c, batch, x0, ref, ref_len, ref_stride, ref_start_dev, u_prev, hull_A, hull_b, hull_nc, hull_sets, hull_sel,
                        u0, status, active, margin);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }
 
 int mpc_prepare(wcqp_mpc_t h) { return h ? ensure_device(h) : WCQP_E_INVALID; }
+void mpc_device_consts(wcqp_mpc_t h, wcqp_mpc::MpcDeviceConsts* c) {
+    c->Gr = h->d_Gr;
+    std::memcpy(c->Gx, h->Gx, sizeof(c->Gx));
+    std::memcpy(c->Gu, h->Gu, sizeof(c->Gu));
+    std::memcpy(c->S0, h->S0, sizeof(c->S0));
+    c->feas_tol = h->p.feas_tol;
+    c->hull_tol = h->p.convex_hull_tolerance;
+    c->N = h->N;
+}
 int mpc_horizon(wcqp_mpc_t h) { return h ? h->N : 0; }
 void mpc_dynamics(wcqp_mpc_t h, double* a, double* b) { *a = h->a; *b = h->b; }
 
@@ -413,7 +273,7 @@ int wcqp_mpc_solve_device(wcqp_mpc_t h, int32_t batch,
                           const double* x0, const double* ref, int32_t ref_len, const double* u_prev,
                           const double* hull_A, const double* hull_b, const int32_t* hull_nc,
                           double* u0, int32_t* status, uint32_t* active, double* margin, void* stream) {
-    return wcqp::mpc_enqueue(h, batch, x0, ref, ref_len, ref_len, nullptr, nullptr, u_prev, hull_A, hull_b, hull_nc, 1, nullptr,
+    return wcqp::mpc_enqueue(h, batch, x0, ref, ref_len, ref_len, nullptr, u_prev, hull_A, hull_b, hull_nc, 1, nullptr,
                              u0, status, active, margin, (hipStream_t)stream);
 }
 

@@ -1,0 +1,178 @@
+// Device side of the DCM-MPC solve, shared by the stand-alone kernel (mpc.hip) and the tick pipeline's fused
+// kernel (ik4.hip with TICK): one QP on the 16 lanes of a DPP row.  Internal, not ABI.
+//
+// Reference path replaced (citations relative to /root/reference/modules/Walking_module):
+//   MPCSolver::{setConstraintsMatrix,setBounds,setGradient,solve,getSolution}   src/MPCSolver.cpp:76-322
+//   WalkingController::solve (u0 read-out + hull-margin check)   src/WalkingDCMModelPredictiveController.cpp:491-521
+// Why this is not an ADMM loop: see mpc.hip.
+#pragma once
+#include <limits>
+#include "wcqp_internal.h"
+
+namespace wcqp_mpc {
+
+constexpr int kLanesPerInstance = 16;   // one DPP row per instance, 4 instances per wave
+constexpr int kInstPerWave = 64 / kLanesPerInstance;
+
+struct MpcDeviceConsts {
+    const double* Gr;     // (N+1) x 2 x 2
+    double Gx[4], Gu[4], S0[4];
+    double feas_tol, hull_tol;
+    int N;
+};
+
+#if defined(__HIPCC__)
+// candidate 0: no row; 1..8: single row e = id-1; 9..36: row pairs (e < f)
+__device__ const unsigned char kPairE[28] = {0,0,0,0,0,0,0, 1,1,1,1,1,1, 2,2,2,2,2, 3,3,3,3, 4,4,4, 5,5, 6};
+__device__ const unsigned char kPairF[28] = {1,2,3,4,5,6,7, 2,3,4,5,6,7, 3,4,5,6,7, 4,5,6,7, 5,6,7, 6,7, 7};
+constexpr int kNumCand = 1 + 8 + 28;
+
+// One DPP move of both halves of a double inside a row of 16 lanes (= one instance here).
+template <int CTRL>
+__device__ __forceinline__ double row_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int row_move(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// the four butterfly partners inside a row: xor 1, xor 2 (quad permutes), then half-mirror and
+// mirror, which pair quads / octets whose lanes already agree
+#define WCQP_ROW_STEPS(X) X(0xB1) X(0x4E) X(0x141) X(0x140)
+
+// One MPC QP on the 16 lanes of a DPP row (t = lane inside the row).  `rp`: the instance's reference window
+// (stages >= ref_len repeat the last one, MPCSolver.cpp:200-214), `hset`: index of the hull row set, `s_hull`: 8 x 4
+// doubles of LDS owned by this row.  Every lane of the row returns the same u0, status, active mask and margin.
+// All 64 lanes of the wave must call it together (wave-level early out, LDS fences).
+__device__ __forceinline__ void mpc_row_solve(const MpcDeviceConsts& c, int t, long inst,
+                                              const double* __restrict__ x0, const double2* __restrict__ rp, int ref_len,
+                                              const double* __restrict__ u_prev,
+                                              const double* __restrict__ hull_A, const double* __restrict__ hull_b,
+                                              const int* __restrict__ hull_nc, long hset, double (*s_hull)[4],
+                                              double& u0x, double& u0y, int& status, unsigned& active, double& margin_out)
+{
+    // ---- u0_unc = sum_i Gr_i r_i + Gx x0 + Gu u_prev ---------------------------------
+    const double2* gp = reinterpret_cast<const double2*>(c.Gr);
+    double ux = 0.0, uy = 0.0;
+    // 64 stages per pass: the four reference loads of a lane (stages t, t+16, t+32, t+48) are
+    // issued back to back before any is consumed, so one HBM round trip covers the whole window
+    // of the N = 50 benchmark instead of four serialized ones
+    for (int base = 0; base <= c.N; base += 4 * kLanesPerInstance) {
+        double2 r[4], g0[4], g1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + t + k * kLanesPerInstance;
+            const int ic = i <= c.N ? i : c.N;                // clamped: stays in bounds, weight zeroed below
+            const int ir = ic < ref_len ? ic : ref_len - 1;   // MPCSolver.cpp:200-214 (constant tail)
+            r[k] = rp[ir];
+            g0[k] = gp[2 * ic]; g1[k] = gp[2 * ic + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double m = (base + t + k * kLanesPerInstance) <= c.N ? 1.0 : 0.0;
+            ux = fma(m * g0[k].x, r[k].x, fma(m * g0[k].y, r[k].y, ux));
+            uy = fma(m * g1[k].x, r[k].x, fma(m * g1[k].y, r[k].y, uy));
+        }
+    }
+    if (t == 0) {
+        const double2 xs = reinterpret_cast<const double2*>(x0)[inst];
+        const double2 up = reinterpret_cast<const double2*>(u_prev)[inst];
+        ux += c.Gx[0] * xs.x + c.Gx[1] * xs.y + c.Gu[0] * up.x + c.Gu[1] * up.y;
+        uy += c.Gx[2] * xs.x + c.Gx[3] * xs.y + c.Gu[2] * up.x + c.Gu[3] * up.y;
+    }
+    // hull rows -> LDS (lanes 0..7 of the instance own one row each)
+    int nc = hull_nc[hset];
+    nc = nc < 0 ? 0 : (nc > WCQP_HULL_ROWS ? WCQP_HULL_ROWS : nc);
+    double rax = 0.0, ray = 0.0, rb = 0.0, rn = 0.0;    // this lane's own hull row (lanes 0..7)
+    if (t < WCQP_HULL_ROWS) {
+        const double2 a = reinterpret_cast<const double2*>(hull_A)[hset * WCQP_HULL_ROWS + t];
+        rb = hull_b[hset * WCQP_HULL_ROWS + t];
+        rax = a.x; ray = a.y; rn = sqrt(a.x * a.x + a.y * a.y);
+        s_hull[t][0] = rax; s_hull[t][1] = ray; s_hull[t][2] = rb; s_hull[t][3] = rn;
+    }
+    // butterfly over the row (DPP, no LDS-pipe round trips): every lane ends with the same sum
+#define WCQP_SUM_STEP(C) ux += row_move<C>(ux); uy += row_move<C>(uy);
+    WCQP_ROW_STEPS(WCQP_SUM_STEP)
+#undef WCQP_SUM_STEP
+    wcqp::wave_lds_fence();
+
+    // ---- projection onto the polygon in the Sigma0^-1 metric --------------------------
+    const double s00 = c.S0[0], s01 = c.S0[1], s10 = c.S0[2], s11 = c.S0[3];
+    double best_cost = std::numeric_limits<double>::infinity();
+    double best_x = ux, best_y = uy;
+    unsigned best_mask = 0;
+    int best_id = kNumCand;
+    // Early out (wave-uniform): when the unconstrained optimum of every instance of this wave
+    // already satisfies its hull rows, candidate 0 wins by construction (cost 0, lowest id) and the
+    // 37-candidate enumeration is skipped.  Same feasibility test as the enumeration applies to
+    // candidate 0, so the result is identical either way.
+    const bool row_violated = t < nc && (rax * ux + ray * uy - rb) > c.feas_tol;
+    if (__ballot(row_violated) == 0ull) {
+        best_cost = 0.0; best_id = 0;
+    } else
+    for (int id = t; id < kNumCand; id += kLanesPerInstance) {
+        int e = -1, f = -1;
+        if (id >= 1 && id <= 8) e = id - 1;
+        else if (id > 8) { e = kPairE[id - 9]; f = kPairF[id - 9]; }
+        if (e >= nc || f >= nc) continue;
+        double px = ux, py = uy, cost = 0.0;
+        unsigned mask = 0;
+        bool ok = true;
+        if (e >= 0) {
+            const double aex = s_hull[e][0], aey = s_hull[e][1];
+            const double sex = s00 * aex + s01 * aey, sey = s10 * aex + s11 * aey;   // Sigma0 a_e
+            const double ree = aex * sex + aey * sey;
+            const double re  = aex * ux + aey * uy - s_hull[e][2];
+            mask = 1u << e;
+            if (f < 0) {
+                ok = ree > 0.0;
+                const double mu = ok ? re * wcqp::fast_rcp(ree) : 0.0;
+                px = ux - sex * mu; py = uy - sey * mu;
+                cost = mu * re;
+            } else {
+                const double afx = s_hull[f][0], afy = s_hull[f][1];
+                const double sfx = s00 * afx + s01 * afy, sfy = s10 * afx + s11 * afy;
+                const double rff = afx * sfx + afy * sfy;
+                const double ref_ = aex * sfx + aey * sfy;
+                const double rf  = afx * ux + afy * uy - s_hull[f][2];
+                const double det = ree * rff - ref_ * ref_;
+                ok = det > 1e-12 * ree * rff;                 // parallel rows have no vertex
+                const double idet = ok ? wcqp::fast_rcp(det) : 0.0;
+                const double mue = (rff * re - ref_ * rf) * idet;
+                const double muf = (ree * rf - ref_ * re) * idet;
+                px = ux - sex * mue - sfx * muf; py = uy - sey * mue - sfy * muf;
+                cost = mue * re + muf * rf;
+                mask |= 1u << f;
+            }
+        }
+        for (int k = 0; k < nc; ++k) {
+            const double res = s_hull[k][0] * px + s_hull[k][1] * py - s_hull[k][2];
+            ok = ok && (k == e || k == f || res <= c.feas_tol);
+        }
+        if (ok && (cost < best_cost || (cost == best_cost && id < best_id))) {
+            best_cost = cost; best_x = px; best_y = py; best_mask = mask; best_id = id;
+        }
+    }
+#define WCQP_MIN_STEP(C) {                                                              \
+        const double oc = row_move<C>(best_cost), ox = row_move<C>(best_x), oy = row_move<C>(best_y); \
+        const int om = row_move<C>((int)best_mask), oi = row_move<C>(best_id);                 \
+        if (oc < best_cost || (oc == best_cost && oi < best_id)) {                             \
+            best_cost = oc; best_x = ox; best_y = oy; best_mask = (unsigned)om; best_id = oi;  \
+        } }
+    WCQP_ROW_STEPS(WCQP_MIN_STEP)
+#undef WCQP_MIN_STEP
+    // signed distance to the hull boundary (computeMargin semantics): every row lane evaluates its
+    // own row, row-min by DPP
+    double margin = (t < nc && rn > 0.0) ? (rb - rax * best_x - ray * best_y) / rn : std::numeric_limits<double>::infinity();
+#define WCQP_MARGIN_STEP(C) margin = fmin(margin, row_move<C>(margin));
+    WCQP_ROW_STEPS(WCQP_MARGIN_STEP)
+#undef WCQP_MARGIN_STEP
+    int st = best_id < kNumCand ? WCQP_STATUS_SOLVED : WCQP_STATUS_INFEASIBLE;
+    // WalkingController::solve: computeMargin(u0) < -tolerance => failure (cpp:513-517)
+    if (st == WCQP_STATUS_SOLVED && margin < -c.hull_tol) st = WCQP_STATUS_OUTSIDE_HULL;
+    u0x = best_x; u0y = best_y; status = st; active = best_mask; margin_out = margin;
+    wcqp::wave_lds_fence();            // s_hull may be reused by the caller
+}
+#endif
+
+}  // namespace wcqp_mpc

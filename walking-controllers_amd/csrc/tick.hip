@@ -24,13 +24,13 @@ using namespace wcqp_tick;
 __global__ void tick_glue_kernel(TickDev d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.batch) return;
-    const int t = *d.tick_latched;       // copy made by the MPC kernel of this tick
+    const int t = d.tick2[d.phase];
     const int code = d.sel[i];
     const int st = d.mpc_status[i];
     const bool ok = st == WCQP_STATUS_SOLVED || st == WCQP_STATUS_OUTSIDE_HULL;
     if (!ok) d.mpc_fail[i] += 1;
     double* s = d.state + (size_t)i * kStateLen;
-    for (int ax = 0; ax < 2; ++ax) tick_glue_axis(d, i, t, ax, ok, s[66 + ax], s[69 + ax], s[72 + ax]);
+    for (int ax = 0; ax < 2; ++ax) tick_glue_axis(d, i, t, ax, ok, d.u0[2 * i + ax], s[66 + ax], s[69 + ax], s[72 + ax]);
     tick_glue_height(d, s);
     for (int k = 0; k < 6; ++k) tick_glue_twist(d, i, code, k, s[75 + k], s[81 + k]);
 }
@@ -39,11 +39,11 @@ __global__ void tick_post_kernel(TickDev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.batch * kDof) return;
     const int i = g / kDof;
-    const int t = *d.tick_latched;
+    const int t = d.tick2[d.phase];
     const bool ok = d.ik_status[i] == WCQP_STATUS_SOLVED;
     tick_post_joint(d, i, t, g % kDof, ok, d.dq[g]);
     if (g % kDof == 0) tick_post_instance(d, i, t, ok);
-    if (g == 0) *d.tick = t + 1;      // advanceReferenceSignals (WalkingModule.cpp:816); nobody reads `tick` any more this tick
+    if (g == 0) d.tick2[1 - d.phase] = t + 1;      // advanceReferenceSignals (WalkingModule.cpp:816)
 }
 
 }  // namespace
@@ -61,6 +61,7 @@ struct wcqp_tick_s {
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;
     bool uploaded = false;
+    int ticks_enqueued = 0;  // since the last upload; its parity is the `phase` of the next tick
     bool fused = false;      // glue + post inside the 16-lane IK kernel: 2 launches per tick instead of 4
     bool base_elim = false;  // the fused kernel is the base-eliminated one (ik4.hip)
 };
@@ -77,17 +78,20 @@ int dev_alloc(wcqp_tick_s* h, T** out, size_t count) {
     return WCQP_OK;
 }
 
-int enqueue_tick(wcqp_tick_s* h, hipStream_t s) {
-    const TickDev& d = h->d;
+// one tick with the given phase (= parity of the tick index: see TickDev::tick2)
+int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s) {
+    TickDev d = h->d;
+    d.phase = phase & 1;
     const int B = d.batch;
     const int N = wcqp::mpc_horizon(h->mpc);
-    int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick, d.tick_latched, d.u_prev,
-                               d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, 3, d.sel,
-                               d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
-    if (rc != WCQP_OK) return rc;
+    // base-eliminated IK kernel: MPC, glue, IK and post step in ONE launch
     if (h->fused && h->base_elim)
         return wcqp_ik::ik4_launch_tick(wcqp::ik_device_params(h->ik), d, h->J_left, h->J_right, h->J_neck, h->J_com,
                                         h->ik_lo, h->ik_up, s);
+    int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick2 + d.phase, d.u_prev,
+                               d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, 3, d.sel,
+                               d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
+    if (rc != WCQP_OK) return rc;
     if (h->fused)
         return wcqp_ik::ik3_launch_tick(wcqp::ik_device_params(h->ik), d, h->J_left, h->J_right, h->J_neck, h->J_com,
                                         h->ik_lo, h->ik_up, s);
@@ -148,13 +152,15 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     A_(d.dcm, B * 2); A_(d.com, B * 2); A_(d.zmp_meas, B * 2); A_(d.u_prev, B * 2); A_(d.u0, B * 2);
     A_(d.c_ref, B * 2); A_(d.v_ref, B * 2); A_(d.v_ref_prev, B * 2); A_(d.p_star, B * 2); A_(d.v_star_prev, B * 2);
     A_(d.q_des, B * kDof); A_(d.dq_prev, B * kDof); A_(d.dq, B * kDof);
-    A_(d.sel, B); A_(d.tick_latched, 1);
+    A_(d.sel, B);
     A_(d.state, B * kStateLen); A_(d.mpc_status, B); A_(d.ik_status, B); A_(d.mpc_fail, B); A_(d.ik_fail, B);
-    A_(d.tick, 1); A_(d.u0_log, (size_t)d.log_ticks * B * 2); A_(d.dq_log, (size_t)d.log_ticks * B * kDof);
+    A_(d.tick2, 2); A_(d.u0_log, (size_t)d.log_ticks * B * 2); A_(d.dq_log, (size_t)d.log_ticks * B * kDof);
     A_(h->J_left, B * 6 * 29); A_(h->J_right, B * 6 * 29); A_(h->J_neck, B * 3 * 29); A_(h->J_com, B * 3 * 29);
     A_(h->mpc_active, B); A_(h->mpc_margin, B); A_(h->ik_lo, B); A_(h->ik_up, B);
 #undef A_
     if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
+    wcqp::mpc_device_consts(h->mpc, &d.mpc);
+    d.horizon = N; d.hull_sets = 3;
     d.ref_traj = ref; d.hull_tab_A = hA; d.hull_tab_b = hb; d.hull_tab_nc = hn; d.phase0 = ph; d.swing_twist = sw;
     *out = h;
     return WCQP_OK;
@@ -190,7 +196,7 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     UP_(d.zmp_meas, in->u_init, B * 16); UP_(d.u_prev, in->u_init, B * 16);
 #undef UP_
     WCQP_HIP_TRY(hipMemset(d.v_ref_prev, 0, B * 16)); WCQP_HIP_TRY(hipMemset(d.v_star_prev, 0, B * 16));
-    WCQP_HIP_TRY(hipMemset(d.dq_prev, 0, B * kDof * 8)); WCQP_HIP_TRY(hipMemset(d.tick, 0, 4));
+    WCQP_HIP_TRY(hipMemset(d.dq_prev, 0, B * kDof * 8)); WCQP_HIP_TRY(hipMemset(d.tick2, 0, 8));
     {   // contact pair of tick 0 (later ticks: tick_post_kernel)
         std::vector<int> sel(B);
         for (size_t i = 0; i < B; ++i) {
@@ -201,26 +207,33 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     }
     WCQP_HIP_TRY(hipMemset(d.mpc_fail, 0, B * 8)); WCQP_HIP_TRY(hipMemset(d.ik_fail, 0, B * 8));
     h->uploaded = true;
+    h->ticks_enqueued = 0;
     return WCQP_OK;
 }
 
 int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream) {
     if (!h || n_ticks < 0 || !h->uploaded) return WCQP_E_INVALID;
+    // the trajectories hold max_ticks + N + 1 stages per instance: a tick beyond that would read its neighbour's
+    if ((long)h->ticks_enqueued + n_ticks > (long)h->p.max_ticks) return WCQP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (!use_graph) {
-        for (int k = 0; k < n_ticks; ++k) { const int rc = enqueue_tick(h, s); if (rc != WCQP_OK) return rc; }
-        return WCQP_OK;
-    }
     // kGraphTicks ticks per graph (the tick index lives in HBM, so the graph is tick-invariant): one
-    // hipGraphLaunch costs about as much as four plain launches, a tick is only two
+    // hipGraphLaunch costs about as much as four plain launches.  The graph is captured with phases 0, 1, 0, ...
+    // and therefore replayed only from an even tick index; an odd one takes a plain tick first.
     constexpr int kGraphTicks = 8;
-    if (!h->graph_exec && n_ticks >= kGraphTicks) {
+    int left = n_ticks;
+    auto plain = [&]() -> int {
+        const int rc = enqueue_tick(h, h->ticks_enqueued & 1, s);
+        if (rc == WCQP_OK) { ++h->ticks_enqueued; --left; }
+        return rc;
+    };
+    if (use_graph && left >= kGraphTicks + 1 && (h->ticks_enqueued & 1)) { const int rc = plain(); if (rc != WCQP_OK) return rc; }
+    if (use_graph && !h->graph_exec && left >= kGraphTicks) {
         hipStream_t cs = nullptr;
         WCQP_HIP_TRY(hipStreamCreate(&cs));
         // (lazy device state of the solver handles exists since create: capture forbids allocations)
         WCQP_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int rc = WCQP_OK;
-        for (int k = 0; k < kGraphTicks && rc == WCQP_OK; ++k) rc = enqueue_tick(h, cs);
+        for (int k = 0; k < kGraphTicks && rc == WCQP_OK; ++k) rc = enqueue_tick(h, k & 1, cs);
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(cs, &g);
         (void)hipStreamDestroy(cs);
@@ -229,9 +242,10 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         h->graph = g;
         WCQP_HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
     }
-    int left = n_ticks;
-    for (; h->graph_exec && left >= kGraphTicks; left -= kGraphTicks) WCQP_HIP_TRY(hipGraphLaunch(h->graph_exec, s));
-    for (; left > 0; --left) { const int rc = enqueue_tick(h, s); if (rc != WCQP_OK) return rc; }
+    if (use_graph && h->graph_exec && !(h->ticks_enqueued & 1)) {
+        for (; left >= kGraphTicks; left -= kGraphTicks, h->ticks_enqueued += kGraphTicks) WCQP_HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+    }
+    while (left > 0) { const int rc = plain(); if (rc != WCQP_OK) return rc; }
     return WCQP_OK;
 }
 
@@ -243,7 +257,7 @@ int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
 #define DN_(dst, src, n) if (dst) WCQP_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
     DN_(out->u0_log, d.u0_log, (size_t)d.log_ticks * B * 16); DN_(out->dq_log, d.dq_log, (size_t)d.log_ticks * B * kDof * 8);
     DN_(out->q_des, d.q_des, B * kDof * 8); DN_(out->dcm, d.dcm, B * 16); DN_(out->com, d.com, B * 16);
-    DN_(out->mpc_fail, d.mpc_fail, B * 8); DN_(out->ik_fail, d.ik_fail, B * 8); DN_(out->tick, d.tick, 4);
+    DN_(out->mpc_fail, d.mpc_fail, B * 8); DN_(out->ik_fail, d.ik_fail, B * 8); DN_(out->tick, d.tick2 + (h->ticks_enqueued & 1), 4);
 #undef DN_
     return WCQP_OK;
 }

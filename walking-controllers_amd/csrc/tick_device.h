@@ -7,6 +7,7 @@
 //   src/WalkingModule.cpp:816       advanceReferenceSignals               -> tick counter in HBM
 #pragma once
 #include "wcqp_internal.h"
+#include "mpc_device.h"
 
 namespace wcqp_tick {
 
@@ -22,14 +23,17 @@ struct TickDev {
     double *q_des, *dq_prev, *dq, *state;
     int *sel, *mpc_status, *ik_status;     // sel: contact pair of the CURRENT tick (0 left, 1 right, 2 both)
     long long *mpc_fail, *ik_fail;
-    int* tick;          // ticks completed; read by the MPC window and the glue
-    int* tick_latched;  // copy made by the MPC kernel of the tick: what the later kernels of the tick read, so
-                        // that the last of them may advance `tick` while some of its workgroups have not started
+    int* tick2;         // ticks completed, kept TWICE: the kernels of a tick read tick2[phase], the last of them writes
+    int phase;          // tick2[1 - phase] = tick + 1 and the next tick runs with the other phase (a host-side
+                        // parity: nobody reads the word that is being written, so one kernel may do both)
     double *u0_log, *dq_log;
     // scalars
     int batch, first, traj_len, log_ticks, step_ticks, ds_ticks;
     double omega, a, b, dT, k_com, k_zmp, noise, com_height;
     unsigned long long seed;
+    // MPC fused into the IK kernel (one launch per tick): its condensed constants and hull-row tables
+    wcqp_mpc::MpcDeviceConsts mpc;
+    int horizon, hull_sets;
 };
 
 #if defined(__HIPCC__)
@@ -54,7 +58,7 @@ __device__ __forceinline__ int contact_code(int t, int phase0, int step_ticks, i
 
 // One horizontal axis of instance i at tick t: reference LIPM integrator, ZMP-CoM law, desired CoM
 // for the IK state block (returned: the caller stores it to HBM or LDS), synthetic plant.  `mpc_ok`: this tick's MPC ended usable.
-__device__ __forceinline__ void tick_glue_axis(const TickDev& d, int i, int t, int ax, bool mpc_ok,
+__device__ __forceinline__ void tick_glue_axis(const TickDev& d, int i, int t, int ax, bool mpc_ok, double u0_ax,
                                                double& s_com, double& s_pstar, double& s_vel) {
     // StableDCMModel::integrateModel (StableDCMModel.cpp:63-90), Tustin integrator; it precedes the
     // MPC in the reference (WalkingModule.cpp:578-597) but only the ZMP-CoM law below consumes it
@@ -64,7 +68,7 @@ __device__ __forceinline__ void tick_glue_axis(const TickDev& d, int i, int t, i
     d.c_ref[2 * i + ax] = c_ref;
     d.v_ref_prev[2 * i + ax] = vr;
     d.v_ref[2 * i + ax] = vr;
-    const double u = mpc_ok ? d.u0[2 * i + ax] : d.u_prev[2 * i + ax];     // hold the last command on failure
+    const double u = mpc_ok ? u0_ax : d.u_prev[2 * i + ax];     // hold the last command on failure
     // WalkingZMPController::evaluateControl (WalkingZMPController.cpp:146-173)
     const double com = d.com[2 * i + ax];
     const double v = d.k_com * (c_ref - com) - d.k_zmp * (u - d.zmp_meas[2 * i + ax]) + vr;

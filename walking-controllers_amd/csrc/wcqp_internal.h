@@ -16,7 +16,9 @@
         }                                                                          \
     } while (0)
 
+namespace wcqp_mpc { struct MpcDeviceConsts; }
 namespace wcqp {
+void mpc_device_consts(wcqp_mpc_t h, wcqp_mpc::MpcDeviceConsts* c);   // kernel-argument copy of the condensed constants (after mpc_prepare)
 
 // Dense LU with partial pivoting, row-major, in place; returns false when singular.
 bool lu_factor(std::vector<double>& a, int n, std::vector<int>& piv);
@@ -32,7 +34,7 @@ struct DeviceScratch {
 
 // internal launch of the MPC kernel with a strided / offset reference window (tick pipeline)
 int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, int ref_len, int ref_stride,
-                const int* ref_start_dev, int* ref_start_copy_dev, const double* u_prev,
+                const int* ref_start_dev, const double* u_prev,
                 const double* hull_A, const double* hull_b, const int* hull_nc, int hull_sets, const int* hull_sel,
                 double* u0, int* status, unsigned* active, double* margin, hipStream_t stream);
 int mpc_horizon(wcqp_mpc_t h);
