@@ -316,6 +316,17 @@ typedef struct wcqp_tick_params {
     uint64_t seed;
     wcqp_mpc_params mpc;
     wcqp_ik_params ik;
+    /* Per-tick kinematics (SURVEY.md 8f-4 inside the tick, WM/src/WalkingModule.cpp:715, 396-410): when set, every tick
+     * first evaluates the forward kinematics of `kin` at the integrated joint positions q_des with the floating base
+     * anchored at the stance foot of the current step (world_T_base = desired sole pose x inverse of the sole's pose in
+     * the base frame: WalkingFK::evaluateWorldToBaseTransformation, WM/src/WalkingForwardKinematics.cpp:160-256), writes
+     * the four MIXED Jacobians and the actual foot / neck poses the IK of the tick reads, and rebuilds the
+     * support-polygon rows from the DESIRED foot poses (state0 entries 24..47, `foot_rect`) whenever an instance's
+     * contact pair changes (setConvexHullConstraint, ...PredictiveController.cpp:364-435).  Two launches per tick
+     * (kinematics, solve).  The J_* and hull_tab_* inputs are then ignored (may be NULL). */
+    int32_t use_kinematics;
+    wcqp_kin_params kin;
+    double  foot_rect[8];       /* corners (x, y) x 4 of the foot rectangle in the foot frame (foot_size, cpp:295-303) */
 } wcqp_tick_params;
 
 typedef struct wcqp_tick_inputs {   /* HOST pointers, copied at upload */

@@ -34,6 +34,8 @@ import dataclasses
 import numpy as np
 
 from . import qp_spec as qs
+from . import kin_spec as ks
+from . import hull_spec as hs
 
 _M1 = np.uint64(0x9E3779B97F4A7C15)
 _M2 = np.uint64(0xBF58476D1CE4E5B9)
@@ -81,9 +83,17 @@ def contact_code(t: int, phase0: np.ndarray, p: TickParams) -> np.ndarray:
     return np.where(s < p.ds_ticks, 2, side).astype(np.int32)
 
 
-def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, ik_form: str = "qpoases"):
-    """data: the arrays of walking-controllers_amd/synth.py::synth_tick_batch.  Returns the
-    per-tick logs u0[T][B][2], dq[T][B][23] and the final states."""
+def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, ik_form: str = "qpoases",
+              kin_model: dict | None = None, foot_rect=None):
+    """data: the arrays of walking-controllers_amd/synth.py::synth_tick_batch (or synth_walk_batch with
+    `kin_model`).  Returns the per-tick logs u0[T][B][2], dq[T][B][23] and the final states.
+
+    kin_model (a table as in kin_spec): per-tick kinematics, the way the reference does it - forward kinematics at the
+    integrated joint positions (WM/src/WalkingModule.cpp:715) and four fresh Jacobians / actual poses for the IK
+    (:396-410), with the floating base anchored at the stance foot of the current step: world_T_base = desired sole
+    pose x (sole pose in the base frame)^-1 (WalkingFK::evaluateWorldToBaseTransformation,
+    WM/src/WalkingForwardKinematics.cpp:160-256); the support-polygon rows are rebuilt from the DESIRED foot poses
+    whenever the contact pair changes (...PredictiveController.cpp:364-435)."""
     B = data["q0"].shape[0]
     N = p.horizon
     mp = qs.MPCParams(horizon=N, sampling_time=p.dT, com_height=p.com_height, gravity=p.gravity)
@@ -97,8 +107,30 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
     q_des = data["q0"].copy(); dq_prev = np.zeros((B, 23))
     u0_log = np.zeros((n_ticks, B, 2)); dq_log = np.zeros((n_ticks, B, 23))
     mpc_fail = np.zeros(B, np.int64); ik_fail = np.zeros(B, np.int64)
+    use_kin = kin_model is not None
+    state_now = data["state0"].copy()
+    hull_cur = [None] * B; hull_code = -np.ones(B, np.int64)
+    J_now = [None] * B
+    active_log = []
     for t in range(n_ticks):
         code = contact_code(t, data["phase0"], p)
+        if use_kin:
+            ident = np.concatenate([np.zeros(3), np.eye(3).reshape(9)])
+            for i in range(B):
+                side = int(((t + int(data["phase0"][i])) % (2 * p.step_ticks)) // p.step_ticks)   # 0: left is the stance foot
+                pa, Ra = ks.forward(kin_model, ident, q_des[i])["frames"][side]
+                sd = state_now[i][36:48] if side else state_now[i][24:36]
+                Rb = sd[3:12].reshape(3, 3) @ Ra.T
+                base = np.concatenate([sd[0:3] - Rb @ pa, Rb.reshape(9)])
+                K = ks.jacobians(kin_model, base, q_des[i])
+                J_now[i] = K
+                s = state_now[i]
+                s[0:3] = K["p_left"]; s[3:12] = K["R_left"].reshape(9); s[12:15] = K["p_right"]; s[15:24] = K["R_right"].reshape(9)
+                s[48:57] = K["R_neck"].reshape(9); s[66:69] = K["com"]
+                if int(code[i]) != hull_code[i]:
+                    k = int(code[i])
+                    hull_cur[i] = hs.hull_from_feet(foot_rect, s[24:36], s[36:48], {0: 1, 1: 2, 2: 3}[k])
+                    hull_code[i] = k
         r_t = data["ref_traj"][:, t, :]
         # LIPM reference (StableDCMModel.cpp:63-90)
         v_ref = -omega * (c_ref - r_t)
@@ -106,10 +138,12 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
         u0 = np.zeros((B, 2))
         for i in range(B):
             k = int(code[i])
-            nc = int(data["hull_tab_nc"][i, k])
+            if use_kin:
+                hA, hb, nc = hull_cur[i]
+            else:
+                hA, hb, nc = data["hull_tab_A"][i, k], data["hull_tab_b"][i, k], int(data["hull_tab_nc"][i, k])
             try:
-                r = qs.mpc_exact(c, dcm[i], data["ref_traj"][i, t:t + N + 1], u_prev[i],
-                                 data["hull_tab_A"][i, k], data["hull_tab_b"][i, k], nc)
+                r = qs.mpc_exact(c, dcm[i], data["ref_traj"][i, t:t + N + 1], u_prev[i], hA, hb, nc)
                 u0[i] = r["u0"]
             except qs.QPOracleError:
                 u0[i] = u_prev[i]; mpc_fail[i] += 1
@@ -118,15 +152,21 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
         p_star = p_star + 0.5 * p.dT * (v_star + v_star_prev); v_star_prev = v_star
         dq = np.zeros((B, 23))
         for i in range(B):
-            s = data["state0"][i].copy()
-            s[66:68] = com[i]; s[68] = p.com_height
-            s[69:71] = p_star[i]; s[71] = p.com_height
+            s = state_now[i].copy()
+            if use_kin:
+                # the IK's "actual" CoM is the forward kinematics' at the desired joint state (WalkingModule.cpp:715,
+                # 373-376), not the plant's; the desired height is the initial one
+                s[69:71] = p_star[i]; s[71] = data["state0"][i][68]
+            else:
+                s[66:68] = com[i]; s[68] = p.com_height
+                s[69:71] = p_star[i]; s[71] = p.com_height
             s[72:74] = v_star[i]; s[74] = 0.0
             k = int(code[i])
             s[75:81] = 0.0 if k in (0, 2) else data["swing_twist"][i]      # left foot in contact -> zero twist
             s[81:87] = 0.0 if k in (1, 2) else data["swing_twist"][i]
-            one = dict(J_left=data["J_left"][i:i + 1], J_right=data["J_right"][i:i + 1], J_neck=data["J_neck"][i:i + 1],
-                       J_com=data["J_com"][i:i + 1], q=q_des[i:i + 1], state=s[None, :])
+            Jsrc = {n: J_now[i][n][None] for n in ("J_left", "J_right", "J_neck", "J_com")} if use_kin else \
+                   {n: data[n][i:i + 1] for n in ("J_left", "J_right", "J_neck", "J_com")}
+            one = dict(q=q_des[i:i + 1], state=s[None, :], **Jsrc)
             try:
                 dq[i] = qs.ik_exact(ik_params, qs.ik_inputs_from_batch(one, 0), ik_form)["dq"]
             except qs.QPOracleError:

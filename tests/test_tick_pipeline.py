@@ -103,3 +103,47 @@ def test_tick_run_refuses_to_run_past_the_trajectories(wca):
     pipe.upload(d)                       # upload rewinds
     pipe.run(T, use_graph=True)
     assert np.array_equal(pipe.download()["dq_log"], want["dq_log"])
+
+
+def _walk_scenario(wca, B, T, first=0):
+    """A coherent synthetic robot marching in place (synth_walk_batch): poses from the device kinematics at tick 0."""
+    kin = wca.KinModel(wca.synth.icub_like_model())
+    kb = wca.synth.synth_walk_kin_batch(B, first=first)
+    poses = kin.jacobians_host(kb["base"], kb["q"], state=np.zeros((B, 87)))["state"]
+    return kin, wca.synth.synth_walk_batch(B, T, poses, kb, first=first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ik_algorithm", [0, 4], ids=["kin+fused_solve", "kin+mpc+ik"])
+def test_tick_pipeline_with_per_tick_kinematics_matches_cpu_restatement(wca, qs, ik_algorithm):
+    """SURVEY 8f-4 inside the tick: every tick evaluates the forward kinematics at the integrated joint
+    state with the base anchored at the stance foot, hands four fresh MIXED Jacobians and the actual poses to the IK
+    (WM/src/WalkingModule.cpp:715, 396-410) and rebuilds the support polygon from the foot poses on a contact change
+    (...PredictiveController.cpp:364-435).  150 closed-loop ticks against oracle/tick_spec.py (kin_spec + hull_spec +
+    the exact QP solvers) at 1e-9; failures (an over-stretched leg makes the IK infeasible) must be the SAME ticks."""
+    from oracle import tick_spec as ts
+    B, T, vmax = 12, 150, 1.0
+    p = ts.TickParams()
+    kin, d = _walk_scenario(wca, B, T)
+    model = wca.synth.icub_like_model()
+    ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax * np.ones(23), joint_reg_deg=wca.synth.WALK_POSTURE_DEG.copy()),
+                       kin_model=model, foot_rect=wca.synth.FOOT_RECT)
+    assert ref["mpc_fail"].sum() == 0
+    # the Jacobians really change: the joints travel
+    assert np.abs(ref["q_des"] - d["q0"]).max() > 0.05
+    for use_graph in (False, True):
+        ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm, joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik, log_ticks=T, kin=kin)
+        pipe.upload(d)
+        pipe.run(T, use_graph=use_graph)
+        out = pipe.download()
+        assert out["tick"] == T and out["mpc_fail"].sum() == 0
+        assert np.array_equal(out["ik_fail"], ref["ik_fail"])
+        assert np.abs(out["u0_log"] - ref["u0_log"]).max() <= 1e-9
+        assert np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8
+        assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9
+        assert np.abs(out["dcm"] - ref["dcm"]).max() <= 1e-9
+        if not use_graph:
+            eager = out
+    assert np.array_equal(out["u0_log"], eager["u0_log"]) and np.array_equal(out["dq_log"], eager["dq_log"])   # graph == eager, bitwise
+    assert np.abs(ref["dq_log"]).max() == pytest.approx(vmax, abs=1e-12)        # velocity limits really bind

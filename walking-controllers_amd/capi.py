@@ -73,7 +73,8 @@ class TickParams(C.Structure):
     _fields_ = [("batch", C.c_int32), ("first", C.c_int32), ("max_ticks", C.c_int32), ("log_ticks", C.c_int32),
                 ("step_ticks", C.c_int32), ("ds_ticks", C.c_int32),
                 ("k_com", C.c_double), ("k_zmp", C.c_double), ("noise", C.c_double), ("seed", C.c_uint64),
-                ("mpc", MpcParams), ("ik", IkParams)]
+                ("mpc", MpcParams), ("ik", IkParams),
+                ("use_kinematics", C.c_int32), ("kin", KinParams), ("foot_rect", C.c_double * 8)]
 
 
 class TickInputs(C.Structure):
@@ -327,10 +328,18 @@ class TickPipeline:
     """Handle over wcqp_tick_* — the device-resident MPC -> glue -> IK tick (configs 4/5)."""
 
     def __init__(self, batch, max_ticks, mpc: MpcSolver, ik: IkSolver, first=0, log_ticks=0,
-                 step_ticks=180, ds_ticks=110, k_com=9.0, k_zmp=3.0, noise=1e-4, seed=99):
+                 step_ticks=180, ds_ticks=110, k_com=9.0, k_zmp=3.0, noise=1e-4, seed=99,
+                 kin: "Optional[KinModel]" = None, foot_rect=None):
+        """kin: a KinModel -> per-tick kinematics (Jacobians, actual poses and hull rows rebuilt every tick from the
+        integrated joint state with the base anchored at the stance foot; upload() then ignores J_* / hull_tab_*)."""
         self.batch, self.max_ticks, self.log_ticks, self.dof = batch, max_ticks, log_ticks, ik.dof
+        self.use_kin = kin is not None
+        if foot_rect is None:
+            from .synth import FOOT_RECT
+            foot_rect = FOOT_RECT
         self.params = TickParams(batch, first, max_ticks, log_ticks, step_ticks, ds_ticks, k_com, k_zmp, noise, seed,
-                                 mpc.params, ik.params)
+                                 mpc.params, ik.params, int(self.use_kin), kin.params if kin is not None else KinParams(),
+                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)))
         self._h = C.c_void_p()
         check(lib().wcqp_tick_create(C.byref(self.params), C.byref(self._h)), "wcqp_tick_create")
         self._keep = None
@@ -347,13 +356,14 @@ class TickPipeline:
             pass
 
     def upload(self, data: dict):
-        f64 = ("ref_traj", "hull_tab_A", "hull_tab_b", "J_left", "J_right", "J_neck", "J_com", "state0",
-               "swing_twist", "q0", "dcm0", "com0", "u_init")
+        f64 = ("ref_traj", "state0", "swing_twist", "q0", "dcm0", "com0", "u_init")
+        f64 += () if self.use_kin else ("hull_tab_A", "hull_tab_b", "J_left", "J_right", "J_neck", "J_com")
         keep = {k: _f64(data[k]) for k in f64}
-        keep["hull_tab_nc"] = np.ascontiguousarray(data["hull_tab_nc"], dtype=np.int32)
+        if not self.use_kin:
+            keep["hull_tab_nc"] = np.ascontiguousarray(data["hull_tab_nc"], dtype=np.int32)
         keep["phase0"] = np.ascontiguousarray(data["phase0"], dtype=np.int32)
         assert keep["ref_traj"].shape == (self.batch, self.max_ticks + self.params.mpc.horizon + 1, 2), keep["ref_traj"].shape
-        ins = TickInputs(**{k: keep[k].ctypes.data for k, _ in TickInputs._fields_})
+        ins = TickInputs(**{k: (keep[k].ctypes.data if k in keep else None) for k, _ in TickInputs._fields_})
         check(lib().wcqp_tick_upload(self._h, C.byref(ins)), "wcqp_tick_upload")
 
     def run(self, n_ticks: int, use_graph: bool = True, stream: int = 0):

@@ -6,6 +6,7 @@
 //            src/WalkingDCMModelPredictiveController.cpp:364-489 (iDynTree ConvexHullHelpers upstream).
 #include <cmath>
 #include "wcqp_internal.h"
+#include "hull_device.h"
 
 namespace {
 
@@ -20,46 +21,10 @@ __global__ void hull_from_feet_kernel(int batch, const double* __restrict__ rect
     const unsigned c = contact[inst];
     for (int f = 0; f < 2; ++f) {
         if (!((c >> f) & 1u)) continue;
-        const double* T = (f == 0 ? left_T : right_T) + (size_t)inst * 12;
-        for (int k = 0; k < 4; ++k) {
-            const double x = rect[2 * k], y = rect[2 * k + 1];
-            // foot-frame corner (x, y, 0) -> world, projected on the XY plane through the origin
-            px[np] = T[3] * x + T[4] * y + T[0];
-            py[np] = T[6] * x + T[7] * y + T[1];
-            ++np;
-        }
+        // foot-frame corner (x, y, 0) -> world, projected on the XY plane through the origin
+        wcqp_hull::foot_points(rect, (f == 0 ? left_T : right_T) + (size_t)inst * 12, px, py, np);
     }
-    double* A = hull_A + (size_t)inst * 16;
-    double* b = hull_b + (size_t)inst * 8;
-    for (int k = 0; k < 8; ++k) { A[2 * k] = 0.0; A[2 * k + 1] = 0.0; b[k] = 1e30; }
-    if (np < 3) { hull_nc[inst] = 0; return; }
-    // insertion sort by (x, y), then Andrew's monotone chain (collinear points dropped)
-    for (int i = 1; i < np; ++i) {
-        const double x = px[i], y = py[i];
-        int j = i - 1;
-        while (j >= 0 && (px[j] > x || (px[j] == x && py[j] > y))) { px[j + 1] = px[j]; py[j + 1] = py[j]; --j; }
-        px[j + 1] = x; py[j + 1] = y;
-    }
-    double hx[16], hy[16];
-    int k = 0;
-    for (int i = 0; i < np; ++i) {                                  // lower hull
-        while (k >= 2 && (hx[k - 1] - hx[k - 2]) * (py[i] - hy[k - 2]) - (hy[k - 1] - hy[k - 2]) * (px[i] - hx[k - 2]) <= 0) --k;
-        hx[k] = px[i]; hy[k] = py[i]; ++k;
-    }
-    const int lower = k + 1;
-    for (int i = np - 2; i >= 0; --i) {                             // upper hull
-        while (k >= lower && (hx[k - 1] - hx[k - 2]) * (py[i] - hy[k - 2]) - (hy[k - 1] - hy[k - 2]) * (px[i] - hx[k - 2]) <= 0) --k;
-        hx[k] = px[i]; hy[k] = py[i]; ++k;
-    }
-    const int nc = k - 1;                                           // last point == first point
-    for (int e = 0; e < nc; ++e) {
-        const double dx = hx[e + 1] - hx[e], dy = hy[e + 1] - hy[e];
-        const double len = sqrt(dx * dx + dy * dy);
-        const double ax = dy / len, ay = -dx / len;                 // outward normal of a CCW edge
-        A[2 * e] = ax; A[2 * e + 1] = ay;
-        b[e] = ax * hx[e] + ay * hy[e];
-    }
-    hull_nc[inst] = nc;
+    hull_nc[inst] = wcqp_hull::hull_rows(px, py, np, hull_A + (size_t)inst * 16, hull_b + (size_t)inst * 8);
 }
 
 }  // namespace

@@ -195,9 +195,9 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         if (80 + j < kStateLen) st[80 + j] = sreg[5];
         if constexpr (TICK) {
             wcqp::wave_lds_fence();
-            if (j < 2) { st[66 + j] = g_com; st[69 + j] = g_pstar; st[72 + j] = g_vel; }
+            if (j < 2) { if (!td.kin_mode) st[66 + j] = g_com; st[69 + j] = g_pstar; st[72 + j] = g_vel; }
             if (j < 6) { st[75 + j] = g_twl; st[81 + j] = g_twr; }
-            if (j == 0) wcqp_tick::tick_glue_height(td, st);
+            if (j == 0) wcqp_tick::tick_glue_height(td, (int)inst, st);
         }
     }
     wcqp::wave_lds_fence();

@@ -19,6 +19,8 @@
 #include <new>
 #include <vector>
 #include "wcqp_internal.h"
+#include "tick_device.h"
+#include "hull_device.h"
 
 namespace {
 
@@ -54,11 +56,14 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 // (slot 32 = root link), FR [3][12] attached frames, CT [4] total first moment / mass
 constexpr int OFF_TW = 0, OFF_MC = 32 * 12, OFF_FR = OFF_MC + 33 * 4, OFF_CT = OFF_FR + 36, PER_INST = OFF_CT + 4;
 
+// TICK: the tick pipeline's per-tick call (WalkingModule.cpp:715, 396-410): base pose from the plant, support-polygon
+// rows rebuilt on a contact change (tick_device.h: KinTick)
+template <bool TICK>
 __global__ __launch_bounds__(64)
 void kin_jacobians_kernel(const KinDev* __restrict__ md, int batch,
                           const double* __restrict__ base, const double* __restrict__ q,
                           double* __restrict__ JL, double* __restrict__ JR, double* __restrict__ JN, double* __restrict__ JC,
-                          double* __restrict__ state)
+                          double* __restrict__ state, wcqp_tick::KinTick kt)
 {
     __shared__ __attribute__((aligned(16))) double smem[2][PER_INST];
     const int lane = threadIdx.x, half = lane >> 5, i = lane & 31;
@@ -74,11 +79,19 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, int batch,
     // base pose
     double pb[3], Rb[9];
     {
-        const double* b = base + inst * 12;
+        if constexpr (TICK) {
+            // the tree is walked in base coordinates first; the base pose follows from the anchor foot below
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pb[k] = b[k];
+            for (int k = 0; k < 3; ++k) pb[k] = 0.0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rb[k] = b[3 + k];
+            for (int k = 0; k < 9; ++k) Rb[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        } else {
+            const double* b = base + inst * 12;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pb[k] = b[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rb[k] = b[3 + k];
+        }
     }
     // own joint: local rotation R0 * Rot(axis, q)   (Rodrigues)
     double Rloc[9], p0[3], ax[3];
@@ -130,6 +143,53 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, int batch,
             for (int k = 0; k < 9; ++k) T[k] = Rw[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) T[9 + k] = pw[k];
+        }
+        wcqp::wave_lds_fence();
+    }
+    if constexpr (TICK) {
+        // anchor foot: its sole frame in base coordinates, then world_T_base = world_T_sole,desired * (base_T_sole)^-1
+        const int t_now = kt.tick2[kt.phase];
+        const int side = ((t_now + kt.phase0[inst]) % (2 * kt.step_ticks)) / kt.step_ticks;     // 0: left is the stance foot
+        const int jf = md->frame_joint[side];
+        const double* T = S + OFF_TW + jf * 12;
+        double Rj[9], fR[9], fp[3], Ra[9], pa[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { Rj[k] = T[k]; fR[k] = md->frame_R[side][k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fp[k] = md->frame_p[side][k];
+        mat3_mul(Rj, fR, Ra);
+        mat3_vec(Rj, fp, d);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pa[k] = T[9 + k] + d[k];
+        const double* sd = state + inst * kStateLen + (side ? 36 : 24);      // desired pose of the anchor sole: p (3), R (9)
+        double Rd[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rd[k] = sd[3 + k];
+        // Rb = Rd Ra'
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Rb[3 * r + c] = Rd[3 * r] * Ra[3 * c] + Rd[3 * r + 1] * Ra[3 * c + 1] + Rd[3 * r + 2] * Ra[3 * c + 2];
+        mat3_vec(Rb, pa, d);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pb[k] = sd[k] - d[k];
+        // this lane's joint frame, now in world coordinates
+        double Rl[9], pl[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rl[k] = Rw[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pl[k] = pw[k];
+        mat3_mul(Rb, Rl, Rw);
+        mat3_vec(Rb, pl, d);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pw[k] = pb[k] + d[k];
+        wcqp::wave_lds_fence();               // every lane has read the base-frame tree: it may be overwritten
+        if (is_joint) {
+            double* Tm = S + OFF_TW + j * 12;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Tm[k] = Rw[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Tm[9 + k] = pw[k];
         }
         wcqp::wave_lds_fence();
     }
@@ -256,6 +316,23 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, int batch,
         if (i < 9) s[48 + i] = S[OFF_FR + 24 + i];            // neck orientation
         if (i < 3) s[66 + i] = ctot[i];                       // CoM position
     }
+    if constexpr (TICK) {
+        // setConvexHullConstraint: the rows change only when the contact pair does (cpp:369-374); they are built
+        // from the DESIRED foot transforms (the planned footsteps, WalkingModule.cpp:609-613), entries 24..47 of the
+        // pose block
+        if (i == 0 && live) {
+            const int code = kt.sel[inst];
+            if (code != kt.sel_built[inst]) {
+                const double* sd = state + inst * kStateLen;
+                double px[8], py[8];
+                int np = 0;
+                if (code == 0 || code == 2) wcqp_hull::foot_points(kt.rect, sd + 24, px, py, np);
+                if (code == 1 || code == 2) wcqp_hull::foot_points(kt.rect, sd + 36, px, py, np);
+                kt.hull_nc[inst] = wcqp_hull::hull_rows(px, py, np, kt.hull_A + inst * 16, kt.hull_b + inst * 8);
+                kt.sel_built[inst] = code;
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -282,6 +359,20 @@ int ensure_device(wcqp_kin_s* h) {
 }
 
 }  // namespace
+
+namespace wcqp {
+int kin_prepare(wcqp_kin_t h) { return h ? ensure_device(h) : WCQP_E_INVALID; }
+int kin_enqueue_tick(wcqp_kin_t h, int batch, const wcqp_tick::KinTick& kt, const double* q,
+                     double* J_left, double* J_right, double* J_neck, double* J_com, double* state, hipStream_t stream) {
+    if (!h || !h->d_model || batch < 1 || !state || !q || !J_left || !J_right || !J_neck || !J_com) return WCQP_E_INVALID;
+    if (!kt.tick2 || !kt.phase0 || !kt.sel || !kt.sel_built || !kt.hull_A || !kt.hull_b || !kt.hull_nc || kt.step_ticks < 1) return WCQP_E_INVALID;
+    const unsigned grid = (unsigned)((batch + 1) / 2);
+    hipLaunchKernelGGL(kin_jacobians_kernel<true>, dim3(grid), dim3(64), 0, stream, h->d_model, batch, nullptr, q,
+                       J_left, J_right, J_neck, J_com, state, kt);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+}  // namespace wcqp
 
 extern "C" {
 
@@ -344,8 +435,8 @@ int wcqp_kin_jacobians_device(wcqp_kin_t h, int32_t batch, const double* base, c
     const int rc = ensure_device(h);
     if (rc != WCQP_OK) return rc;
     const unsigned grid = (unsigned)((batch + 1) / 2);
-    hipLaunchKernelGGL(kin_jacobians_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, h->d_model, batch, base, q,
-                       J_left, J_right, J_neck, J_com, state);
+    hipLaunchKernelGGL(kin_jacobians_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, h->d_model, batch, base, q,
+                       J_left, J_right, J_neck, J_com, state, wcqp_tick::KinTick{});
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }

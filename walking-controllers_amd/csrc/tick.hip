@@ -30,8 +30,12 @@ __global__ void tick_glue_kernel(TickDev d) {
     const bool ok = st == WCQP_STATUS_SOLVED || st == WCQP_STATUS_OUTSIDE_HULL;
     if (!ok) d.mpc_fail[i] += 1;
     double* s = d.state + (size_t)i * kStateLen;
-    for (int ax = 0; ax < 2; ++ax) tick_glue_axis(d, i, t, ax, ok, d.u0[2 * i + ax], s[66 + ax], s[69 + ax], s[72 + ax]);
-    tick_glue_height(d, s);
+    for (int ax = 0; ax < 2; ++ax) {
+        double g_com;
+        tick_glue_axis(d, i, t, ax, ok, d.u0[2 * i + ax], g_com, s[69 + ax], s[72 + ax]);
+        if (!d.kin_mode) s[66 + ax] = g_com;
+    }
+    tick_glue_height(d, i, s);
     for (int k = 0; k < 6; ++k) tick_glue_twist(d, i, code, k, s[75 + k], s[81 + k]);
 }
 
@@ -64,6 +68,8 @@ struct wcqp_tick_s {
     int ticks_enqueued = 0;  // since the last upload; its parity is the `phase` of the next tick
     bool fused = false;      // glue + post inside the 16-lane IK kernel: 2 launches per tick instead of 4
     bool base_elim = false;  // the fused kernel is the base-eliminated one (ik4.hip)
+    wcqp_kin_t kin = nullptr;     // use_kinematics: Jacobians, actual poses and hull rows are rebuilt every tick
+    KinTick kt{};
 };
 
 namespace {
@@ -84,12 +90,17 @@ int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s) {
     d.phase = phase & 1;
     const int B = d.batch;
     const int N = wcqp::mpc_horizon(h->mpc);
+    if (h->kin) {
+        h->kt.phase = d.phase;
+        const int rck = wcqp::kin_enqueue_tick(h->kin, B, h->kt, d.q_des, h->J_left, h->J_right, h->J_neck, h->J_com, d.state, s);
+        if (rck != WCQP_OK) return rck;
+    }
     // base-eliminated IK kernel: MPC, glue, IK and post step in ONE launch
     if (h->fused && h->base_elim)
         return wcqp_ik::ik4_launch_tick(wcqp::ik_device_params(h->ik), d, h->J_left, h->J_right, h->J_neck, h->J_com,
                                         h->ik_lo, h->ik_up, s);
     int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick2 + d.phase, d.u_prev,
-                               d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, 3, d.sel,
+                               d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, d.hull_sets, d.hull_sets > 1 ? d.sel : nullptr,
                                d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
     if (rc != WCQP_OK) return rc;
     if (h->fused)
@@ -127,6 +138,11 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
                 params->ik.algorithm == WCQP_IK_ALG_BASE_ELIM);
     int rc = wcqp_mpc_create(&params->mpc, &h->mpc);
     if (rc == WCQP_OK) rc = wcqp_ik_create(&params->ik, &h->ik);
+    if (rc == WCQP_OK && params->use_kinematics) {
+        if (params->kin.dof != kDof) rc = WCQP_E_UNSUPPORTED;
+        if (rc == WCQP_OK) rc = wcqp_kin_create(&params->kin, &h->kin);
+        if (rc == WCQP_OK) rc = wcqp::kin_prepare(h->kin);
+    }
     if (rc == WCQP_OK) rc = wcqp::mpc_prepare(h->mpc);
     if (rc == WCQP_OK) rc = wcqp::ik_prepare(h->ik);
     if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
@@ -148,7 +164,8 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     int *hn = nullptr, *ph = nullptr;
     rc = WCQP_OK;
 #define A_(ptr, n) if (rc == WCQP_OK) rc = dev_alloc(h, &(ptr), (n))
-    A_(ref, B * d.traj_len * 2); A_(hA, B * 3 * 16); A_(hb, B * 3 * 8); A_(hn, B * 3); A_(ph, B); A_(sw, B * 6);
+    const size_t hsets = params->use_kinematics ? 1 : 3;       // kinematics mode: one live row set per instance, rebuilt on a contact change
+    A_(ref, B * d.traj_len * 2); A_(hA, B * hsets * 16); A_(hb, B * hsets * 8); A_(hn, B * hsets); A_(ph, B); A_(sw, B * 6);
     A_(d.dcm, B * 2); A_(d.com, B * 2); A_(d.zmp_meas, B * 2); A_(d.u_prev, B * 2); A_(d.u0, B * 2);
     A_(d.c_ref, B * 2); A_(d.v_ref, B * 2); A_(d.v_ref_prev, B * 2); A_(d.p_star, B * 2); A_(d.v_star_prev, B * 2);
     A_(d.q_des, B * kDof); A_(d.dq_prev, B * kDof); A_(d.dq, B * kDof);
@@ -160,7 +177,15 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
 #undef A_
     if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
     wcqp::mpc_device_consts(h->mpc, &d.mpc);
-    d.horizon = N; d.hull_sets = 3;
+    d.horizon = N; d.hull_sets = (int)hsets;
+    if (h->kin) {
+        int* sb = nullptr; double* h0 = nullptr;
+        if (dev_alloc(h, &sb, B) != WCQP_OK || dev_alloc(h, &h0, B) != WCQP_OK) { wcqp_tick_destroy(h); return WCQP_E_NOMEM; }
+        d.kin_mode = 1; d.com_h0 = h0;
+        h->kt.tick2 = d.tick2; h->kt.phase0 = ph; h->kt.step_ticks = d.step_ticks; h->kt.sel = d.sel; h->kt.sel_built = sb;
+        h->kt.hull_A = hA; h->kt.hull_b = hb; h->kt.hull_nc = hn;
+        std::memcpy(h->kt.rect, params->foot_rect, sizeof(h->kt.rect));
+    }
     d.ref_traj = ref; d.hull_tab_A = hA; d.hull_tab_b = hb; d.hull_tab_nc = hn; d.phase0 = ph; d.swing_twist = sw;
     *out = h;
     return WCQP_OK;
@@ -171,6 +196,7 @@ int wcqp_tick_destroy(wcqp_tick_t h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->kin) wcqp_kin_destroy(h->kin);
     if (h->mpc) wcqp_mpc_destroy(h->mpc);
     if (h->ik) wcqp_ik_destroy(h->ik);
     delete h;
@@ -179,18 +205,25 @@ int wcqp_tick_destroy(wcqp_tick_t h) {
 
 int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     if (!h || !in) return WCQP_E_INVALID;
-    if (!in->ref_traj || !in->hull_tab_A || !in->hull_tab_b || !in->hull_tab_nc || !in->phase0 || !in->J_left ||
-        !in->J_right || !in->J_neck || !in->J_com || !in->state0 || !in->swing_twist || !in->q0 || !in->dcm0 ||
-        !in->com0 || !in->u_init) return WCQP_E_INVALID;
+    if (!in->ref_traj || !in->phase0 || !in->state0 || !in->swing_twist || !in->q0 || !in->dcm0 || !in->com0 || !in->u_init) return WCQP_E_INVALID;
+    if (!h->kin && (!in->hull_tab_A || !in->hull_tab_b || !in->hull_tab_nc || !in->J_left || !in->J_right || !in->J_neck || !in->J_com))
+        return WCQP_E_INVALID;
     TickDev& d = h->d;
     const size_t B = (size_t)d.batch;
     WCQP_HIP_TRY(hipDeviceSynchronize());
 #define UP_(dst, src, n) WCQP_HIP_TRY(hipMemcpy((void*)(dst), (src), (n), hipMemcpyHostToDevice))
-    UP_(d.ref_traj, in->ref_traj, B * d.traj_len * 16); UP_(d.hull_tab_A, in->hull_tab_A, B * 3 * 128);
-    UP_(d.hull_tab_b, in->hull_tab_b, B * 3 * 64); UP_(d.hull_tab_nc, in->hull_tab_nc, B * 3 * 4);
+    UP_(d.ref_traj, in->ref_traj, B * d.traj_len * 16);
     UP_(d.phase0, in->phase0, B * 4); UP_(d.swing_twist, in->swing_twist, B * 48);
-    UP_(h->J_left, in->J_left, B * 6 * 29 * 8); UP_(h->J_right, in->J_right, B * 6 * 29 * 8);
-    UP_(h->J_neck, in->J_neck, B * 3 * 29 * 8); UP_(h->J_com, in->J_com, B * 3 * 29 * 8);
+    if (h->kin) {
+        WCQP_HIP_TRY(hipMemset(h->kt.sel_built, 0xff, B * 4));       // -1: every instance builds its rows at tick 0
+        std::vector<double> h0(B);
+        for (size_t i = 0; i < B; ++i) h0[i] = in->state0[i * kStateLen + 68];       // desired CoM height = the initial one
+        WCQP_HIP_TRY(hipMemcpy((void*)d.com_h0, h0.data(), B * 8, hipMemcpyHostToDevice));
+    } else {
+        UP_(d.hull_tab_A, in->hull_tab_A, B * 3 * 128); UP_(d.hull_tab_b, in->hull_tab_b, B * 3 * 64); UP_(d.hull_tab_nc, in->hull_tab_nc, B * 3 * 4);
+        UP_(h->J_left, in->J_left, B * 6 * 29 * 8); UP_(h->J_right, in->J_right, B * 6 * 29 * 8);
+        UP_(h->J_neck, in->J_neck, B * 3 * 29 * 8); UP_(h->J_com, in->J_com, B * 3 * 29 * 8);
+    }
     UP_(d.state, in->state0, B * kStateLen * 8); UP_(d.q_des, in->q0, B * kDof * 8);
     UP_(d.dcm, in->dcm0, B * 16); UP_(d.com, in->com0, B * 16); UP_(d.c_ref, in->com0, B * 16); UP_(d.p_star, in->com0, B * 16);
     UP_(d.zmp_meas, in->u_init, B * 16); UP_(d.u_prev, in->u_init, B * 16);

@@ -34,7 +34,36 @@ struct TickDev {
     // MPC fused into the IK kernel (one launch per tick): its condensed constants and hull-row tables
     wcqp_mpc::MpcDeviceConsts mpc;
     int horizon, hull_sets;
+    // per-tick kinematics: the IK's ACTUAL CoM (pose block 66..68) is the forward kinematics' at the desired joint
+    // state (WalkingModule.cpp:715, 373-376), not the plant's, and the desired height is the
+    // instance's initial one
+    int kin_mode;
+    const double* com_h0;     // [B]
 };
+
+// Per-tick kinematics (wcqp_tick_params::use_kinematics): what the kinematics kernel needs beyond the model when it
+// runs inside the tick.  The joints are the integrated q_des; the floating base is ANCHORED at the stance foot of the
+// current step, the way the reference does it (WalkingFK::evaluateWorldToBaseTransformation with the fixed foot,
+// WM/src/WalkingForwardKinematics.cpp:160-256, called at WM/src/WalkingModule.cpp:560-576): world_T_base =
+// world_T_sole,desired * (base_T_sole(q))^-1, so the stance sole sits exactly on its planned pose and the base moves
+// as the stance leg's joints do.  The support-polygon rows are rebuilt from the DESIRED foot poses whenever the
+// contact pair changes (WalkingController::setConvexHullConstraint, ...PredictiveController.cpp:364-435).
+struct KinTick {
+    const int* tick2; int phase;      // tick index (TickDev::tick2)
+    const int* phase0; int step_ticks;   // anchor foot = stance foot of the step: ((t + phase0) % (2 step_ticks)) / step_ticks
+    const int* sel;           // [B] contact pair of this tick (0 left, 1 right, 2 both)
+    int* sel_built;           // [B] contact pair the current hull rows were built for (-1: none yet)
+    double* hull_A; double* hull_b; int* hull_nc;     // [B][8][2], [B][8], [B]
+    double rect[8];           // foot rectangle corners (x, y) x 4 in the foot frame
+};
+
+}  // namespace wcqp_tick
+namespace wcqp {
+// the kinematics kernel in tick mode (kin.hip)
+int kin_enqueue_tick(wcqp_kin_t h, int batch, const wcqp_tick::KinTick& kt, const double* q,
+                     double* J_left, double* J_right, double* J_neck, double* J_com, double* state, hipStream_t stream);
+}  // namespace wcqp
+namespace wcqp_tick {
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
@@ -91,8 +120,9 @@ __device__ __forceinline__ void tick_glue_twist(const TickDev& d, int i, int cod
     tw_left = (code == 0 || code == 2) ? 0.0 : tw;      // -> state[75 + k]
     tw_right = (code == 1 || code == 2) ? 0.0 : tw;     // -> state[81 + k]
 }
-__device__ __forceinline__ void tick_glue_height(const TickDev& d, double* s) {
-    s[68] = d.com_height; s[71] = d.com_height; s[74] = 0.0;
+__device__ __forceinline__ void tick_glue_height(const TickDev& d, int i, double* s) {
+    if (d.kin_mode) { s[71] = d.com_h0[i]; s[74] = 0.0; }
+    else { s[68] = d.com_height; s[71] = d.com_height; s[74] = 0.0; }
 }
 // joint jj of instance i after the IK of tick t: q <- Integrator(dq) (WalkingModule.cpp:741-744)
 __device__ __forceinline__ void tick_post_joint(const TickDev& d, int i, int t, int jj, bool ik_ok, double dq) {

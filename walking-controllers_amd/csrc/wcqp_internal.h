@@ -43,6 +43,7 @@ int ik_prepare(wcqp_ik_t h);
 const void* ik_device_params(wcqp_ik_t h);     // IkDeviceParams* in HBM (after ik_prepare)
 bool ik_fast_ok(wcqp_ik_t h);                  // the handle qualifies for the base-eliminated kernel (ik4.hip)
 void mpc_dynamics(wcqp_mpc_t h, double* a, double* b);
+int kin_prepare(wcqp_kin_t h);
 
 // ---- wave-level helpers used by the kernels (gfx950, wave64) -------------------------
 #if defined(__HIPCC__)

@@ -30,6 +30,8 @@ IK_STATE_OFFSETS = dict(
 
 FOOT_X = (-0.02, 0.05)       # controllerParams.ini:7  foot_size
 FOOT_Y = (-0.025, 0.025)
+# the four corners (x, y) of the foot rectangle in the foot frame, in the order foot_corners() walks them
+FOOT_RECT = np.array([FOOT_X[1], FOOT_Y[1], FOOT_X[1], FOOT_Y[0], FOOT_X[0], FOOT_Y[0], FOOT_X[0], FOOT_Y[1]])
 NOMINAL_WIDTH = 0.16         # plannerParams.ini:27
 
 ICUB_JOINT_REG_DEG = np.array([15, 0, 0,
@@ -37,6 +39,16 @@ ICUB_JOINT_REG_DEG = np.array([15, 0, 0,
                                -7, 22, 11, 30,
                                5.082, 0.406, -0.131, -45.249, -26.454, -0.351,
                                5.082, 0.406, -0.131, -45.249, -26.454, -0.351], float)
+
+# Posture the WALK scenario (synth_walk_batch, per-tick kinematics) starts from and regularises to.  The shipped
+# jointRegularization (ICUB_JOINT_REG_DEG) belongs to the real iCub URDF, which is not in the repository: on the
+# iCub-SHAPED tree of icub_like_model() it puts the soles 15 cm ahead of the centre of mass and tilts them by 65 degrees,
+# a robot no LIPM can balance.  This is the tree's own crouch: thighs 35 deg forward, knees 70 deg (room to stretch a leg while the pelvis sways over the other foot), soles flat under the CoM.
+WALK_POSTURE_DEG = np.array([5, 0, 0,
+                             -7, 22, 11, 30,
+                             -7, 22, 11, 30,
+                             -35.0, 0.406, -0.131, 70.0, -35.0, -0.351,
+                             -35.0, 0.406, -0.131, 70.0, -35.0, -0.351], float)
 
 _M1 = np.uint64(0x9E3779B97F4A7C15)
 _M2 = np.uint64(0xBF58476D1CE4E5B9)
@@ -261,6 +273,28 @@ def synth_ik_batch(count: int, seed: int = 4321, dof: int = 23, first: int = 0,
 
 
 # --------------------------------------------------------------------------------------
+def _dcm_reference(zl, zr, phase0, T, step_ticks, ds_ticks, dT, com_height, gravity):
+    """ZMP reference that sits on the stance foot's ZMP point (zl / zr) in single support and moves linearly to the
+    next stance foot in double support; DCM reference integrated BACKWARDS through xi_t = (xi_{t+1} - b zmp_t) / a
+    (the way the reference's planner builds it, WM/src/TrajectoryGenerator.cpp:152-154).  Returns (xi[:, :T], zmp[:, :T])."""
+    count = zl.shape[0]
+    Tz = T + 4 * step_ticks                                   # tail so that the backward pass has settled
+    tau = np.arange(Tz)[None, :]
+    cyc = (tau + phase0[:, None]) % (2 * step_ticks)
+    sidx = cyc % step_ticks
+    side = cyc // step_ticks                                  # 0: left is the stance foot of this step
+    cur = np.where(side[..., None] == 0, zl[:, None, :], zr[:, None, :])
+    prev = np.where(side[..., None] == 0, zr[:, None, :], zl[:, None, :])
+    lam = np.clip(sidx / float(ds_ticks), 0.0, 1.0)[..., None]
+    zmp = prev + lam * (cur - prev)
+    a = np.exp(np.sqrt(gravity / com_height) * dT); b = 1.0 - a
+    xi = np.zeros((count, Tz, 2))
+    xi[:, -1] = zmp[:, -1]
+    for t in range(Tz - 2, -1, -1):
+        xi[:, t] = (xi[:, t + 1] - b * zmp[:, t]) / a
+    return np.ascontiguousarray(xi[:, :T]), np.ascontiguousarray(zmp[:, :T])
+
+
 def synth_tick_batch(count: int, n_ticks: int, seed: int = 2718, horizon: int = 50, first: int = 0,
                      step_ticks: int = 180, ds_ticks: int = 110, dT: float = 0.01, com_height: float = 0.53,
                      gravity: float = 9.81):
@@ -295,24 +329,10 @@ def synth_tick_batch(count: int, n_ticks: int, seed: int = 2718, horizon: int = 
         return np.stack([np.cos(a) * v[0] - np.sin(a) * v[1], np.sin(a) * v[0] + np.cos(a) * v[1]], -1)
     zl = left_xy + rot2(yaw[:, 0], (0.03, -0.005))            # leftZMPDelta
     zr = right_xy + rot2(yaw[:, 1], (0.03, 0.005))            # rightZMPDelta
-    Tz = T + 4 * step_ticks                                   # tail so that the backward pass has settled
-    tau = np.arange(Tz)[None, :]
-    cyc = (tau + phase0[:, None]) % (2 * step_ticks)
-    sidx = cyc % step_ticks
-    side = cyc // step_ticks                                  # 0: left is the stance foot of this step
-    cur = np.where(side[..., None] == 0, zl[:, None, :], zr[:, None, :])
-    prev = np.where(side[..., None] == 0, zr[:, None, :], zl[:, None, :])
-    lam = np.clip(sidx / float(ds_ticks), 0.0, 1.0)[..., None]
-    zmp = prev + lam * (cur - prev)
-    a = np.exp(np.sqrt(gravity / com_height) * dT); b = 1.0 - a
-    xi = np.zeros((count, Tz, 2))
-    xi[:, -1] = zmp[:, -1]
-    for t in range(Tz - 2, -1, -1):
-        xi[:, t] = (xi[:, t + 1] - b * zmp[:, t]) / a
-    ref = np.ascontiguousarray(xi[:, :T])
+    ref, zmp = _dcm_reference(zl, zr, phase0, T, step_ticks, ds_ticks, dT, com_height, gravity)
     ik = synth_ik_batch(count, seed=seed + 1, first=first)
     dcm0 = ref[:, 0, :] + dcm_n
-    return dict(first=first, ref_traj=ref, zmp_ref=np.ascontiguousarray(zmp[:, :T]), hull_tab_A=hull_tab_A,
+    return dict(first=first, ref_traj=ref, zmp_ref=zmp, hull_tab_A=hull_tab_A,
                 hull_tab_b=hull_tab_b, hull_tab_nc=hull_tab_nc, phase0=phase0, J_left=ik["J_left"],
                 J_right=ik["J_right"], J_neck=ik["J_neck"], J_com=ik["J_com"], state0=ik["state"],
                 swing_twist=np.ascontiguousarray(swing), q0=ik["q"], dcm0=np.ascontiguousarray(dcm0),
@@ -368,13 +388,61 @@ def icub_like_model() -> dict:
                 frame_R=np.stack([np.eye(3), np.eye(3), _rot_axis(Y, np.deg2rad(5.0))]))
 
 
-def synth_kin_batch(count: int, seed: int = 31415, first: int = 0) -> dict:
+def synth_kin_batch(count: int, seed: int = 31415, first: int = 0, joint_sigma: float = 0.25, posture_deg=None,
+                    base_rot_sigma: float = 0.15) -> dict:
     """Base poses ([B][12]: position, row-major rotation) and joint angles [B][23] around the posture the
-    reference regularises to (ICUB_JOINT_REG_DEG), shard-invariant like the other generators."""
+    reference regularises to (ICUB_JOINT_REG_DEG), shard-invariant like the other generators.  (A walk starts close
+    to that posture - joint_sigma ~0.04 - or the regularisation term alone asks for rad/s of joint velocity.)"""
     rng = CounterRNG(seed, first, count)
-    q = np.deg2rad(ICUB_JOINT_REG_DEG)[None, :] + rng.normal(23, 0.25)
+    q = np.deg2rad(ICUB_JOINT_REG_DEG if posture_deg is None else posture_deg)[None, :] + rng.normal(23, joint_sigma)
     pos = rng.normal(3, 1.0) * np.array([0.05, 0.05, 0.02]) + np.array([0.0, 0.0, 0.55])
-    w = rng.normal(3, 0.15)
+    w = rng.normal(3, base_rot_sigma)
     R = np.stack([_rot_axis(wi / (np.linalg.norm(wi) + 1e-300), np.linalg.norm(wi)) for wi in w])
     base = np.concatenate([pos, R.reshape(count, 9)], axis=1)
     return dict(q=np.ascontiguousarray(q), base=np.ascontiguousarray(base))
+
+
+def synth_walk_kin_batch(count: int, first: int = 0) -> dict:
+    """Base poses / joint angles the walk scenario starts from: robots standing upright on the tree's own crouch
+    (WALK_POSTURE_DEG), a few degrees of scatter."""
+    return synth_kin_batch(count, seed=27182, first=first, joint_sigma=0.03, posture_deg=WALK_POSTURE_DEG, base_rot_sigma=0.03)
+
+
+def synth_walk_batch(count: int, n_ticks: int, poses: np.ndarray, kin_batch: dict, seed: int = 2718, horizon: int = 50,
+                     first: int = 0, step_ticks: int = 180, ds_ticks: int = 110, dT: float = 0.01, com_height: float = 0.53,
+                     gravity: float = 9.81):
+    """Inputs of the tick pipeline WITH per-tick kinematics (`TickPipeline(kin=...)`): a coherent synthetic robot
+    marching in place.  `kin_batch` = synth_walk_kin_batch(count, first=first) (base poses, joint angles), `poses` [count][87] =
+    the pose block the kinematics produce for it at tick 0 (`KinModel.jacobians_host(base, q, state=zeros)["state"]` on
+    the device, or the oracle's twin in the tests): the desired foot poses ARE the initial ones (the feet stay planted;
+    the pipeline anchors the base at the stance foot, so it moves as the stance leg's joints do), the desired neck orientation is the initial one up to a small rotation, the ZMP
+    reference alternates between the two feet's ZMP points (plannerParams.ini:39-40) and the DCM reference follows from it."""
+    rng = CounterRNG(seed ^ 0xA11CE, first, count)
+    T = n_ticks + horizon + 1
+    o = IK_STATE_OFFSETS
+    # the walk starts from standing in the middle of a double-support phase (either foot next), where the DCM reference
+    # passes between the feet - close to where the robot's own CoM is; contact pairs then change every 70-110 ticks
+    u_ph = rng.uniform(2)
+    phase0 = ((u_ph[:, 0] < 0.5) * step_ticks + (0.35 + 0.2 * u_ph[:, 1]) * ds_ticks).astype(np.int32)
+    dcm_n = rng.normal(2, 0.002)
+    swing = rng.normal(6, 0.08)        # a leg of ~0.45 m turns 0.2 m/s into ~0.5 rad/s: keep the swing foot slow
+    neck_w = rng.normal(3, 0.02)
+    state0 = np.array(poses, dtype=np.float64, copy=True)
+    for src, dst, k in (("p_left", "pd_left", 3), ("R_left", "Rd_left", 9), ("p_right", "pd_right", 3), ("R_right", "Rd_right", 9)):
+        state0[:, o[dst]:o[dst] + k] = state0[:, o[src]:o[src] + k]
+    Rn = state0[:, o["R_neck"]:o["R_neck"] + 9].reshape(count, 3, 3)
+    state0[:, o["Rd_neck"]:o["Rd_neck"] + 9] = (_small_rot(neck_w) @ Rn).reshape(count, 9)
+
+    def zmp_point(p_name, R_name, delta):
+        p = state0[:, o[p_name]:o[p_name] + 2]
+        R = state0[:, o[R_name]:o[R_name] + 9].reshape(count, 3, 3)
+        return p + np.stack([R[:, 0, 0] * delta[0] + R[:, 0, 1] * delta[1], R[:, 1, 0] * delta[0] + R[:, 1, 1] * delta[1]], -1)
+    zl = zmp_point("p_left", "R_left", (0.03, -0.005))        # leftZMPDelta
+    zr = zmp_point("p_right", "R_right", (0.03, 0.005))       # rightZMPDelta
+    ref, zmp = _dcm_reference(zl, zr, phase0, T, step_ticks, ds_ticks, dT, com_height, gravity)
+    dcm0 = ref[:, 0, :] + dcm_n
+    return dict(first=first, ref_traj=ref, zmp_ref=zmp, phase0=phase0, state0=np.ascontiguousarray(state0),
+                swing_twist=np.ascontiguousarray(swing), q0=np.ascontiguousarray(kin_batch["q"]),
+                dcm0=np.ascontiguousarray(dcm0),
+                # the plant's CoM starts where the robot's own (kinematic) CoM is
+                com0=np.ascontiguousarray(state0[:, o["com"]:o["com"] + 2].copy()), u_init=np.ascontiguousarray(zmp[:, 0].copy()))
