@@ -57,6 +57,13 @@ def main():
                     help="qp workload: 2 = the (independent) MPC and IK batches go to two HIP streams and may overlap; "
                          "0 = auto: 2 up to 32768 robots per GPU (+18 %% at 4096, +18 %% at 8192, +9 %% at 16384, +2 %% at 32768: the MPC "
                          "kernel fits beside the IK kernel), 1 above (at 65536 the overlap slows the IK kernel more than it saves)")
+    ap.add_argument("--input-sets", type=int, default=0, help="qp workload: distinct input sets visited round-robin (0 = enough for > 320 MB, at least 2)")
+    ap.add_argument("--ik-jac", choices=["mixed", "auto", "general"], default="mixed",
+                    help="wcqp_ik_params.jacobian_structure: mixed = the caller states what the reference always passes (iDynTree MIXED "
+                         "free-floating Jacobians; checked per instance, one launch), auto = + the general kernel over non-conforming "
+                         "instances (one more, nearly empty, launch), general = the general kernel only")
+    ap.add_argument("--tick-tables", action="store_true", help="tick workload: constant uploaded Jacobians and precomputed hull tables "
+                    "(round-1 form) instead of per-tick kinematics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     args = ap.parse_args()
@@ -98,9 +105,15 @@ def main():
         t = torch.from_numpy(np.ascontiguousarray(a))
         return t.to(dev) if dtype is None else t.to(dev, dtype)
 
-    d = {k: up(mb[k]) for k in ("x0", "ref", "u_prev", "hull_A", "hull_b")}
-    d["hull_nc"] = up(mb["hull_nc"])
-    d.update({k: up(ib[k]) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")})
+    base = {k: up(mb[k]) for k in ("x0", "ref", "u_prev", "hull_A", "hull_b")}
+    base["hull_nc"] = up(mb["hull_nc"])
+    base.update({k: up(ib[k]) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")})
+    # K input sets in distinct HBM allocations, visited round-robin, so that every launch reads COLD inputs: one set is
+    # 6.1 KB x B (25 MB at 4096 robots) and would otherwise sit in the 256 MiB Infinity Cache from the previous step.
+    # Set k is the same batch rotated by k B / K instances: same work per launch, different bytes at every address.
+    set_bytes = B * (MPC_BYTES_PER_QP - 16 + IK_BYTES_PER_QP - 184)
+    K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
+    sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
     u0 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
     mstat = torch.zeros(B, dtype=torch.int32, device=dev)
     mact = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -112,7 +125,9 @@ def main():
     iit = torch.zeros(B, dtype=torch.int32, device=dev)
 
     mpc = wca.MpcSolver(horizon=50)
-    ik = wca.IkSolver(form=wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP, v_max=args.ik_vmax)
+    ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
+    jac = {"mixed": wca.IK_JAC_MIXED, "auto": wca.IK_JAC_AUTO, "general": wca.IK_JAC_GENERAL}[args.ik_jac]
+    ik = wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=jac)
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
     n_streams = args.streams if args.streams else (2 if B <= 32768 else 1)
@@ -121,25 +136,26 @@ def main():
     sp_mpc = stream_mpc.cuda_stream
     N1 = mb["ref"].shape[1]
 
-    def launch_mpc():
+    def launch_mpc(d, on=None):
         mpc.solve_device(B, d["x0"].data_ptr(), d["ref"].data_ptr(), N1, d["u_prev"].data_ptr(),
                          d["hull_A"].data_ptr(), d["hull_b"].data_ptr(), d["hull_nc"].data_ptr(),
-                         u0.data_ptr(), mstat.data_ptr(), mact.data_ptr(), mmar.data_ptr(), sp_mpc)
+                         u0.data_ptr(), mstat.data_ptr(), mact.data_ptr(), mmar.data_ptr(), sp_mpc if on is None else on)
 
-    def launch_ik():
-        ik.solve_device(B, d["J_left"].data_ptr(), d["J_right"].data_ptr(), d["J_neck"].data_ptr(),
-                        d["J_com"].data_ptr(), d["q"].data_ptr(), d["state"].data_ptr(),
-                        dq.data_ptr(), istat.data_ptr(), ilo.data_ptr(), iup.data_ptr(), 0, iit.data_ptr(), sp)
+    def launch_ik(d, solver=None):
+        (solver or ik).solve_device(B, d["J_left"].data_ptr(), d["J_right"].data_ptr(), d["J_neck"].data_ptr(),
+                                    d["J_com"].data_ptr(), d["q"].data_ptr(), d["state"].data_ptr(),
+                                    dq.data_ptr(), istat.data_ptr(), ilo.data_ptr(), iup.data_ptr(), 0, iit.data_ptr(), sp)
 
     # optional RCCL exchange (rank 0 owns the whole batch)
     exch = None
     if args.exchange and world > 1:
         in_keys = ("x0", "ref", "u_prev", "hull_A", "hull_b", "J_left", "J_right", "J_neck", "J_com", "q", "state")
+        d0 = sets[0]
         if rank == 0:
-            full = {k: [torch.empty_like(d[k]) for _ in range(world)] for k in in_keys}
+            full = {k: [torch.empty_like(d0[k]) for _ in range(world)] for k in in_keys}
             for k in in_keys:
                 for r in range(world):
-                    full[k][r].copy_(d[k])           # shape-true stand-ins: only the traffic matters here
+                    full[k][r].copy_(d0[k])           # shape-true stand-ins: only the traffic matters here
             gat_u0 = [torch.empty_like(u0) for _ in range(world)]
             gat_dq = [torch.empty_like(dq) for _ in range(world)]
         else:
@@ -147,63 +163,47 @@ def main():
 
         def exch_in():
             for k in in_keys:
-                dist.scatter(d[k], full[k] if rank == 0 else None, src=0)
+                dist.scatter(d0[k], full[k] if rank == 0 else None, src=0)
 
         def exch_out():
             dist.gather(u0, gat_u0 if rank == 0 else None, dst=0)
             dist.gather(dq, gat_dq if rank == 0 else None, dst=0)
         exch = (exch_in, exch_out)
 
-    bracket_ik = [False]      # two streams with fewer than 2 sampled steps: fall back to bracketing the IK launch
-
-    def step(ev=None):
+    def step(i):
+        d = sets[0] if exch else sets[i % K]
         if exch:
             exch[0]()
-        launch_mpc()
-        if ev is not None:
-            ev[0].record(stream)
-        launch_ik()
-        if ev is not None and (not two_streams or bracket_ik[0]):
-            ev[1].record(stream)
+        launch_mpc(d)
+        launch_ik(d)
         if exch:
             exch[1]()
 
     def barrier():
+        # an event per stream, polled: hipDeviceSynchronize alone wakes up ~50 us late, which a 20-step timed region of
+        # 0.35 ms would carry as a 15 % error; the synchronize that follows returns at once
+        evs = [torch.cuda.Event() for _ in range(2)]
+        evs[0].record(stream); evs[1].record(stream_mpc)
+        while not (evs[0].query() and evs[1].query()):
+            pass
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    # the inputs and the zero-filled outputs were enqueued on the default stream: the MPC stream starts behind them
+    stream_mpc.wait_stream(stream)
+    for i in range(args.warmup):
+        step(i)
     barrier()
-    # HIP events around the IK launch of every `stride`-th timed step (a pair of event records costs about
-    # as much as a launch, so bracketing every step would slow the thing being measured).  With two streams
-    # the IK stream carries nothing but IK launches: one event every `stride` steps, and the kernel's
-    # average duration is the time between consecutive events / stride (inter-launch gap included).
-    stride = max(1, int(os.environ.get("WCQP_BENCH_EVENT_STRIDE", str(max(1, min(8, args.steps // 8))))))
-    events = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, stride)}
-    bracket_ik[0] = len(events) < 2
+    # ---- the timed region: K steps, nothing but the launches (no events, no host reads) ----------------------------
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events.get(k))
+    for i in range(args.steps):
+        step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(dist, torch, dev, elapsed)
-    if two_streams and len(events) >= 2:
-        keys = sorted(events)
-        ik_ms = float(np.mean([events[a][0].elapsed_time(events[b][0]) / (b - a) for a, b in zip(keys[:-1], keys[1:])]))
-    else:
-        ik_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))      # IK kernel, HIP events on its stream
-    # MPC kernel duration: a short separately timed run (it is not the dominant kernel)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    e0.record(stream_mpc)
-    for _ in range(50):
-        launch_mpc()
-    e1.record(stream_mpc)
-    torch.cuda.synchronize(dev)
-    mpc_ms = e0.elapsed_time(e1) / 50.0
+    stream.wait_stream(stream_mpc)
 
     # sanity: the timed work really solved the problems
     n_ok_ik = int((istat == 0).sum().item())
@@ -211,8 +211,35 @@ def main():
     ik_iters = float(iit.double().mean().item())
     frac_active = float(((ilo | iup) != 0).double().mean().item())
 
+    # ---- kernel durations, measured AFTER the timed region in short passes of their own: HIP events on the launch
+    # stream around n back-to-back launches of one kernel (a pair of event records costs about as much as a launch, so
+    # nothing is bracketed singly); `cold` rotates over the K input sets like the timed region, `resident` re-reads one
+    def kernel_ms(launch, on, cold, n=None):
+        n = n or max(24, 2 * K)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(K):
+            launch(sets[i % K if cold else 0])
+        torch.cuda.synchronize(dev)
+        e0.record(on)
+        for i in range(n):
+            launch(sets[i % K if cold else 0])
+        e1.record(on)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+    # the IK kernel alone: a MIXED-structure handle launches exactly the one kernel (AUTO adds the nearly empty
+    # fall-back launch behind it, timed separately below)
+    ik_one = ik if args.ik_jac != "auto" else wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=wca.IK_JAC_MIXED)
+    ik_ms = kernel_ms(lambda d: launch_ik(d, ik_one), stream, True)
+    ik_ms_res = kernel_ms(lambda d: launch_ik(d, ik_one), stream, False)
+    mpc_ms = kernel_ms(lambda d: launch_mpc(d, sp), stream, True)
+    mpc_ms_res = kernel_ms(lambda d: launch_mpc(d, sp), stream, False)
+    ik_auto = wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=wca.IK_JAC_AUTO)
+    ik_auto_ms = kernel_ms(lambda d: launch_ik(d, ik_auto), stream, True)
+
     total_qp = 2 * B * world * args.steps
     value = total_qp / elapsed
+    ik_kernel = {"mixed": "ik4_kernel", "auto": "ik4_kernel", "general": "ik3_kernel"}[args.ik_jac]
+    ik_gbs = IK_BYTES_PER_QP * B / (ik_ms * 1e-3) / 1e9
     out = {
         "metric": METRIC, "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -222,20 +249,26 @@ def main():
                          "(iCub 23 DoF, 15 eq rows, %s form, v_max=%.2f rad/s) B=%d; 2 QP solves per robot-tick"
                          % (B, args.ik_form, args.ik_vmax, B)),
             "batch_per_gpu": B, "global_batch": B * world, "horizon": 50, "dof": 23,
+            "input_sets": K, "input_bytes_per_set": set_bytes, "ik_jacobian_structure": args.ik_jac,
             "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ""),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "ik3_kernel",
-            "achieved": IK_BYTES_PER_QP * B / (ik_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": IK_BYTES_PER_QP * B / (ik_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": ik_kernel,
+            "achieved": ik_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ik_gbs / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": ik_ms, "algorithmic_bytes_per_launch": IK_BYTES_PER_QP * B,
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (> the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6),
+            "frac_resident_inputs": IK_BYTES_PER_QP * B / (ik_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": ik_ms_res,
         },
         "kernels": {
             "ik_ms": ik_ms, "ik_qps_per_gpu": B / (ik_ms * 1e-3),
-            # secondary bound: ~30 kflop per IK-QP (elimination 13.5 k, Gram product 8.1 k, sweep 5.5 k,
-            # tables / x / active set ~3 k) against the 78.6 TFLOP/s fp64 vector peak
-            "ik_fp64_tflops": 30e3 * B / (ik_ms * 1e-3) / 1e12, "ik_fp64_frac": 30e3 * B / (ik_ms * 1e-3) / 78.6e12,
-            "mpc_ms": mpc_ms, "mpc_qps_per_gpu": B / (mpc_ms * 1e-3),
+            # secondary bounds.  fp64 vector: ~8.5 kflop per IK-QP with the base-eliminated kernel (row
+            # operations 1.6 k, sweep 2.5 k, x / bounds ~1.4 k, rhs / rot errors ~0.5 k + the Gram tile below) against
+            # 78.6 TFLOP/s; fp64 MFMA: 6 v_mfma_f64_16x16x4 per IK-QP = 12.3 kflop issued (the Gram product C C', 24 x 13 x 13
+            # useful) against the 78.6 TFLOP/s fp64 matrix peak
+            "ik_fp64_valu_frac": 6.0e3 * B / (ik_ms * 1e-3) / 78.6e12,
+            "ik_mfma_f64_tflops": 12288.0 * B / (ik_ms * 1e-3) / 1e12, "ik_mfma_f64_frac": 12288.0 * B / (ik_ms * 1e-3) / 78.6e12,
+            "ik_auto_ms": ik_auto_ms, "ik_auto_fallback_launch_ms": ik_auto_ms - ik_ms,
+            "mpc_ms": mpc_ms, "mpc_ms_resident_inputs": mpc_ms_res, "mpc_qps_per_gpu": B / (mpc_ms * 1e-3),
             "mpc_hbm_frac": MPC_BYTES_PER_QP * B / (mpc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         },
         "solved": {"ik": n_ok_ik, "mpc": n_ok_mpc, "of": B, "ik_mean_active_set_changes": ik_iters,
@@ -321,20 +354,32 @@ def bench_kin(args, wca, torch, dist, dev, world, rank, B, first):
 
 
 def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
-    """BASELINE configs[3]/[4]: every step is one robot-tick of the whole batch — MPC on the
-    receding window of the per-instance DCM trajectory, ZMP-CoM glue, IK, joint integration —
-    with all solver and plant state resident in HBM and the six launches replayed from a hipGraph."""
+    """BASELINE configs[3]/[4]: every step is one robot-tick of the whole batch - per-tick kinematics at the integrated
+    joint state (Jacobians, actual poses, support polygon on a contact change), then MPC on the receding window of the
+    per-instance DCM trajectory, ZMP-CoM glue, IK and joint integration in ONE fused launch - with all solver and
+    plant state resident in HBM and the launches replayed from a hipGraph.  `--tick-tables`: the round-1 form
+    (constant uploaded Jacobians, precomputed hull tables; one launch per tick)."""
     T = args.steps + args.warmup
-    # `--streams 2` (auto from 8192 robots per GPU; measured 39.6 -> 36.2 us per tick there, no gain at 4096): the batch is cut into two independent halves, each its
-    # own pipeline on its own HIP stream, so that one half's (HBM-bound) MPC kernel overlaps the other half's
-    # IK kernel.  Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
+    kin_mode = not args.tick_tables
+    vmax = args.ik_vmax if args.tick_tables else max(args.ik_vmax, 1.0)     # the walking robot needs ~1 rad/s (DESIGN.md)
+    # `--streams 2`: the batch is cut into two independent halves, each its own pipeline on its own HIP stream.
+    # Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
     n_streams = args.streams if args.streams else (2 if B >= 8192 and B % 2 == 0 else 1)
     parts = [(first, B)] if n_streams == 1 else [(first, B // 2), (first + B // 2, B - B // 2)]
     ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
     pipes = []
+    kin = wca.KinModel(wca.synth.icub_like_model()) if kin_mode else None
     for f0, cnt in parts:
-        pp = wca.TickPipeline(cnt, T, wca.MpcSolver(horizon=50), wca.IkSolver(form=ik_form, v_max=args.ik_vmax), first=f0)
-        pp.upload(wca.synth.synth_tick_batch(cnt, T, first=f0))
+        if kin_mode:
+            kb = wca.synth.synth_walk_kin_batch(cnt, first=f0)
+            poses = kin.jacobians_host(kb["base"], kb["q"], state=np.zeros((cnt, 87)))["state"]
+            data = wca.synth.synth_walk_batch(cnt, T, poses, kb, first=f0)
+            iks = wca.IkSolver(form=ik_form, v_max=vmax, joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
+        else:
+            data = wca.synth.synth_tick_batch(cnt, T, first=f0)
+            iks = wca.IkSolver(form=ik_form, v_max=vmax)
+        pp = wca.TickPipeline(cnt, T, wca.MpcSolver(horizon=50), iks, first=f0, kin=kin)
+        pp.upload(data)
         pipes.append(pp)
     stream = torch.cuda.current_stream(dev)
     streams = [stream] + [torch.cuda.Stream(dev) for _ in pipes[1:]]
@@ -367,29 +412,39 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
                  "ik_fail": np.concatenate([x["ik_fail"] for x in states])}
     dev_ms = e0.elapsed_time(e1) / args.steps
     value = 2 * B * world * args.steps / elapsed
-    bytes_per_tick = 6296 + 2 * 8 * (2 * 10 + 23 * 3)      # algorithmic I/O + resident controller/plant state read+written
+    # algorithmic I/O of a tick (6296 B) + resident controller / plant state read and written; with per-tick
+    # kinematics the Jacobians and actual poses are written by one kernel and read by the next (4464 B more)
+    bytes_per_tick = 6296 + 2 * 8 * (2 * 10 + 23 * 3) + (4464 + 280 if kin_mode else 0)
+    launches = ("2 launches: kin_jacobians_kernel<TICK>, ik4_kernel<TICK> with MPC, glue, IK and post step fused" if kin_mode
+                else "1 launch: ik4_kernel<TICK> with MPC, glue, IK and post step fused")
     out = {
         "metric": METRIC, "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[3]/[4] per GPU: receding-horizon robot-tick (DCM-MPC N=50 on the advancing "
+            "workload": ("BASELINE configs[3]/[4] per GPU: receding-horizon robot-tick (%sDCM-MPC N=50 on the advancing "
                          "reference window -> ZMP-CoM glue -> QP-IK 23 DoF %s form v_max=%.2f -> joint integration), "
                          "B=%d robots, %s, contact pair changes every 70-110 ticks; 2 QP solves per robot-tick"
-                         % (args.ik_form, args.ik_vmax, B, "hipGraph replay" if graph else "plain launches")),
-            "batch_per_gpu": B, "global_batch": B * world, "horizon": 50, "dof": 23, "ticks": args.steps,
+                         % ("forward kinematics + Jacobians + support polygon at the integrated joint state -> " if kin_mode else "constant Jacobians, ",
+                            args.ik_form, vmax, B, "hipGraph replay" if graph else "plain launches")),
+            "batch_per_gpu": B, "global_batch": B * world, "horizon": 50, "dof": 23, "ticks": args.steps, "per_tick_kinematics": kin_mode,
             "parallelism": "batch sharded over %d GPU(s), no data-path collective%s" % (world, "; two half-batches on two HIP streams" if len(pipes) > 1 else ""),
         },
-        "roofline": {"bound": "hbm", "kernel": "whole tick (2 launches: mpc_condensed, ik3_kernel<TICK> with glue and post fused)", "achieved": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "whole tick (%s)" % launches, "achieved": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "avg_launch_ms": dev_ms, "algorithmic_bytes_per_launch": bytes_per_tick * B},
         "solved": {"ticks_executed": out_state["tick"], "mpc_fail": int(out_state["mpc_fail"].sum()),
-                   "ik_fail": int(out_state["ik_fail"].sum()), "of": B * T},
+                   "ik_fail": int(out_state["ik_fail"].sum()), "robots_with_ik_fail": int((out_state["ik_fail"] > 0).sum()), "of": B * T},
     }
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def wca_synth_mpc(count, horizon):
+    import walking_controllers_amd as wca
+    return wca.synth.synth_mpc_batch(count, seed=1234, horizon=horizon)
 
 
 def cpu_baseline(mb, ib, args):
@@ -428,10 +483,22 @@ def cpu_baseline(mb, ib, args):
     for _ in range(reps):
         co.ik_batch(ipar, take(ib, n), args.ik_form, nthreads=cores)
     wall_i = time.perf_counter() - t
+    # the MPC as the reference runs it on >= 97 % of its ticks (no contact change): ONE persistent OSQP workspace per
+    # robot, bounds + gradient updated, warm-started solve (WM/src/MPCSolver.cpp:157-173, 249-258).  The number above
+    # (`mpc_qps`) pays set-up, ordering, symbolic + numeric LDL' and scaling for every QP: it is the COLD number (what
+    # the reference pays on a contact change, ...PredictiveController.cpp:415-420).
+    warm_ticks = 40
+    nw = min(n, 2048)
+    wb = wca_synth_mpc(nw, 50 + warm_ticks)
+    _, warm_iters, warm_thread_s, warm_fail = co.mpc_batch_osqp_warm(mp, wb, warm_ticks, nthreads=cores)
+    mpc_warm_qps = nw * warm_ticks / (warm_thread_s / cores) if warm_thread_s > 0 else None
     return {"value": 2 * n * reps / (wall_m + wall_i), "unit": "QP/s", "cores": cores, "kind": "port",
+            "mpc_warm_qps": mpc_warm_qps, "mpc_warm_mean_iters": warm_iters, "mpc_warm_nonconverged": warm_fail,
+            "mpc_warm_sample": "%d robots x %d warm ticks each after one cold solve (set-up not timed): persistent workspace, "
+                               "bounds + gradient update, warm-started OSQP-restatement solve" % (nw, warm_ticks),
             "sample": "%d x the first %d instances of the same workload (1 MPC via OSQP-restatement + 1 IK via %s per instance), "
                       "OpenMP static split" % (reps, n, "dense active set" if args.ik_form == "qpoases" else "OSQP-restatement"),
-            "mpc_qps": n * reps / wall_m, "ik_qps": n * reps / wall_i,
+            "mpc_qps": n * reps / wall_m, "mpc_qps_is": "cold start: a new OSQP workspace per QP", "ik_qps": n * reps / wall_i,
             "single_thread_qps": {"mpc": 1.0 / t_m, "ik": 1.0 / t_i}}
 
 

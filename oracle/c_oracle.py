@@ -73,6 +73,28 @@ def mpc_batch_osqp(mp, batch, nthreads=1):
     return u0, iters, status
 
 
+def mpc_batch_osqp_warm(mp, batch, warm_ticks, nthreads=1):
+    """Warm ticks through one persistent OSQP workspace per instance (update bounds + gradient, warm-started solve):
+    batch["ref"] must hold horizon + 1 + warm_ticks stages.  Returns (u0 of the last tick, mean iterations per warm
+    solve, summed thread-seconds spent in the warm solves, number of warm solves that did not converge)."""
+    p = OrcMpcParams(mp.horizon, mp.sampling_time, mp.com_height, mp.gravity,
+                     (C.c_double * 4)(*np.asarray(mp.Q, float).reshape(-1)),
+                     (C.c_double * 4)(*np.asarray(mp.R, float).reshape(-1)))
+    B = batch["x0"].shape[0]
+    ref = np.ascontiguousarray(batch["ref"], dtype=np.float64)
+    u0 = np.zeros((B, 2))
+    arrs = [np.ascontiguousarray(batch[k], dtype=np.float64) for k in ("x0", "u_prev", "hull_A", "hull_b")]
+    nc = np.ascontiguousarray(batch["hull_nc"], dtype=np.int32)
+    mi, ws = C.c_double(0.0), C.c_double(0.0)
+    f = lib().orc_mpc_batch_osqp_warm
+    f.restype = C.c_int
+    rc = f(C.byref(p), B, int(warm_ticks), _p(arrs[0]), _p(ref), ref.shape[1], _p(arrs[1]), _p(arrs[2]), _p(arrs[3]),
+           _p(nc), _p(u0), C.byref(mi), C.byref(ws), int(nthreads))
+    if rc < 0:
+        raise ValueError("reference window too short for the requested warm ticks")
+    return u0, mi.value, ws.value, rc
+
+
 def ik_batch(ip, batch, form, nthreads=1):
     """ip: oracle.qp_spec.IKParams; form 'qpoases' | 'osqp'.  Returns dq, status, lo, up, iters."""
     def pad(a):

@@ -54,6 +54,9 @@ typedef struct {
     int max_iter, scaling, check_termination, adaptive_rho, adaptive_rho_interval;
 } osqp_settings;
 
+#include <time.h>
+static double now_seconds(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
 static void osqp_default_settings(osqp_settings* s) {
     s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
     s->adaptive_rho_tolerance = 5.0; s->max_iter = 4000; s->scaling = 10; s->check_termination = 25;
@@ -606,6 +609,113 @@ int orc_mpc_batch_osqp(const orc_mpc_params* p, int batch,
         free(xs); osqp_cleanup(w); csc_free(Ac); free(Ad); free(q); free(l); free(u);
     }
     csc_free(Pc);
+    return nfail;
+}
+
+/* MPCSolver::setBounds / setGradient on an EXISTING workspace (MPCSolver.cpp:157-173, 249-258: updateBounds,
+ * updateGradient - osqp_update_bounds / osqp_update_lin_cost upstream): new data in, scaled like the old. */
+static void osqp_update_q(osqp_work* w, const double* q) { for (int j = 0; j < w->n; ++j) w->q[j] = w->c * w->D[j] * q[j]; }
+static void osqp_update_bounds(osqp_work* w, const double* l, const double* u) {
+    for (int i = 0; i < w->m; ++i) {
+        const double li = l[i] < -OSQP_INFTY_ ? -OSQP_INFTY_ : l[i], ui = u[i] > OSQP_INFTY_ ? OSQP_INFTY_ : u[i];
+        w->l[i] = w->E[i] * li; w->u[i] = w->E[i] * ui;
+    }
+}
+
+/* =====================================================================================
+ * MPC batch, WARM ticks: what the reference does on every tick without a contact change (>= 97 % of them): the
+ * OSQP workspace of the previous tick is kept, only the bounds (x0, hull b) and the gradient (reference window
+ * shifted by one stage, u_prev) are updated, and solve() warm-starts from the previous (x, y)
+ * (MPCSolver.cpp:157-173, 216-258, 297-314).  Per instance: one cold set-up + solve (not timed by the caller's
+ * `warm_seconds`), then `warm_ticks` warm solves on a window that advances one stage per tick
+ * (ref must hold ref_len >= N + 1 + warm_ticks stages; x0 follows the LIPM under the applied input).
+ * Returns the number of non-converged warm solves; *warm_seconds = wall time of the warm solves of all threads' work.
+ * ===================================================================================== */
+int orc_mpc_batch_osqp_warm(const orc_mpc_params* p, int batch, int warm_ticks,
+                            const double* x0, const double* ref, int ref_len, const double* u_prev,
+                            const double* hull_A, const double* hull_b, const int* hull_nc,
+                            double* u0_out, double* mean_iters_warm, double* warm_seconds, int nthreads) {
+    const int N = p->N, nx = 2 * (N + 1), nu = 2 * N, n = nx + nu;
+    if (ref_len < N + 1 + warm_ticks) return -1;
+    double* Pd = (double*)calloc((size_t)n * n, sizeof(double));
+    for (int i = 0; i <= N; ++i)
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) Pd[(size_t)(2 * i + r) * n + 2 * i + c] = p->Q[2 * r + c];
+    for (int i = 0; i < N; ++i)
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) {
+            const double Rrc = p->R[2 * r + c];
+            Pd[(size_t)(nx + 2 * i + r) * n + nx + 2 * i + c] += Rrc;
+            if (i + 1 < N) {
+                Pd[(size_t)(nx + 2 * i + r) * n + nx + 2 * i + c] += Rrc;
+                Pd[(size_t)(nx + 2 * i + r) * n + nx + 2 * (i + 1) + c] -= Rrc;
+                Pd[(size_t)(nx + 2 * (i + 1) + r) * n + nx + 2 * i + c] -= Rrc;
+            }
+        }
+    const double omega = sqrt(p->gravity / p->com_height);
+    const double a = exp(omega * p->dT), b = 1.0 - a;
+    csc* Pc = csc_from_dense(Pd, n, n, 1);
+    free(Pd);
+    int nfail = 0;
+    long iters_total = 0;
+    double t_warm = 0.0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static) reduction(+ : nfail, iters_total, t_warm)
+#endif
+    for (int inst = 0; inst < batch; ++inst) {
+        int nc = hull_nc[inst]; nc = nc < 0 ? 0 : (nc > 8 ? 8 : nc);
+        const int m = nx + nc;
+        double* Ad = (double*)calloc((size_t)m * n, sizeof(double));
+        for (int i = 0; i < nx; ++i) Ad[(size_t)i * n + i] = -1.0;
+        for (int i = 0; i < N; ++i)
+            for (int r = 0; r < 2; ++r) {
+                Ad[(size_t)(2 * (i + 1) + r) * n + 2 * i + r] = a;
+                Ad[(size_t)(2 * (i + 1) + r) * n + nx + 2 * i + r] = b;
+            }
+        for (int k = 0; k < nc; ++k) {
+            Ad[(size_t)(nx + k) * n + nx] = hull_A[(size_t)inst * 16 + 2 * k];
+            Ad[(size_t)(nx + k) * n + nx + 1] = hull_A[(size_t)inst * 16 + 2 * k + 1];
+        }
+        double* q = (double*)calloc((size_t)n, sizeof(double));
+        double* l = (double*)calloc((size_t)m, sizeof(double));
+        double* u = (double*)calloc((size_t)m, sizeof(double));
+        double* xs = (double*)malloc(sizeof(double) * n);
+        double xm[2] = {x0[2 * inst], x0[2 * inst + 1]}, up[2] = {u_prev[2 * inst], u_prev[2 * inst + 1]};
+        osqp_work* w = NULL;
+        csc* Ac = csc_from_dense(Ad, m, n, 0);
+        for (int t = 0; t <= warm_ticks; ++t) {
+            for (int i = 0; i <= N; ++i) {
+                const double* r = ref + ((size_t)inst * ref_len + t + i) * 2;
+                q[2 * i] = -(p->Q[0] * r[0] + p->Q[1] * r[1]);
+                q[2 * i + 1] = -(p->Q[2] * r[0] + p->Q[3] * r[1]);
+            }
+            q[nx] = -(p->R[0] * up[0] + p->R[1] * up[1]);
+            q[nx + 1] = -(p->R[2] * up[0] + p->R[3] * up[1]);
+            l[0] = u[0] = -xm[0]; l[1] = u[1] = -xm[1];
+            for (int k = 0; k < nc; ++k) { l[nx + k] = -OSQP_INFTY_; u[nx + k] = hull_b[(size_t)inst * 8 + k]; }
+            int rc;
+            if (t == 0) {
+                osqp_settings st; osqp_default_settings(&st);
+                w = osqp_setup(n, m, Pc, q, Ac, l, u, &st);
+                rc = w->status < 0 ? -1 : osqp_solve(w);
+            } else {
+                const double t0 = now_seconds();
+                osqp_update_bounds(w, l, u);
+                osqp_update_q(w, q);
+                rc = osqp_solve(w);                     /* (x, y, z) of the previous tick are the starting point */
+                t_warm += now_seconds() - t0;
+                iters_total += w->iters;
+                if (rc != 0) nfail++;
+            }
+            osqp_get_x(w, xs);
+            up[0] = xs[nx]; up[1] = xs[nx + 1];
+            xm[0] = a * xm[0] + b * up[0]; xm[1] = a * xm[1] + b * up[1];          /* the plant follows the LIPM */
+        }
+        u0_out[2 * inst] = up[0]; u0_out[2 * inst + 1] = up[1];
+        free(xs); osqp_cleanup(w); csc_free(Ac); free(Ad); free(q); free(l); free(u);
+    }
+    csc_free(Pc);
+    if (mean_iters_warm) *mean_iters_warm = warm_ticks > 0 ? (double)iters_total / ((double)batch * warm_ticks) : 0.0;
+    if (warm_seconds) *warm_seconds = t_warm;
     return nfail;
 }
 
