@@ -204,6 +204,10 @@ typedef struct wcqp_ik_s* wcqp_ik_t;
  * (osqp.cpp:54-133, qp.cpp:53-133, WalkingQPInverseKinematics.cpp:25-116). */
 int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out);
 int wcqp_ik_destroy(wcqp_ik_t h);
+/* WalkingQPIK::setDesiredJointPosition (WalkingQPInverseKinematics.cpp:246-256): replaces the regularisation posture
+ * (rad, `dof` entries) that enters the gradient of every later solve (osqp.cpp:185, qp.cpp:166).  Synchronises the
+ * device; not graph-capturable. */
+int wcqp_ik_set_posture(wcqp_ik_t h, const double* joint_reg_rad);
 
 /*
  * One IK tick for `batch` instances — the solver part of the reference's "IK" bracket

@@ -57,13 +57,17 @@ static int run_mpc(const char* mpcIni) {
         std::deque<Transform> dl{L}, dr{R};
         std::deque<bool> lc{contact[tick][0] != 0}, rc{contact[tick][1] != 0};
         const bool resetTrajectory = tick == 5;
+        // WalkingController::reset (cpp:537-543) at tick 6: the contact pair is the one of tick 5, yet the solver must
+        // be rebuilt (full gradient instead of the shifted one) because reset() cleared the feet status
+        const bool didReset = tick == 6;
+        if (didReset) c.reset();
         Vector2 x; x(0) = dcm.front()(0) + 0.01 * std::cos(1.7 * tick); x(1) = dcm.front()(1) + 0.012 * std::sin(2.3 * tick) + (tick == 10 ? -0.05 : 0.0);
         bool ok = c.setConvexHullConstraint(dl, dr, lc, rc);
         ok = ok && c.setFeedback(x);
         ok = ok && c.setReferenceSignal(dcm, resetTrajectory);
         const bool solved = ok && c.solve();
         Vector2 u; const bool got = solved && c.getControllerOutput(u);
-        std::printf("tick: %d %d %d %d %d %d %d %u\n", tick, contact[tick][0], contact[tick][1], (int)resetTrajectory, (int)solved, (int)got, c.lastStatus, c.lastActive);
+        std::printf("tick: %d %d %d %d %d %d %d %u %d\n", tick, contact[tick][0], contact[tick][1], (int)resetTrajectory, (int)solved, (int)got, c.lastStatus, c.lastActive, (int)didReset);
         line("x0", x.v, 2);
         std::vector<double> flat; for (int i = 0; i <= N && i < (int)dcm.size(); ++i) { flat.push_back(dcm[i](0)); flat.push_back(dcm[i](1)); }
         line("deque", flat.data(), flat.size());
@@ -105,6 +109,9 @@ static int run_ik(const char* ikIni, const char* form) {
         for (int k = 0; k < 3; ++k) { com(k) = 0.02 * g.next() + (k == 2 ? 0.53 : 0); comDes(k) = (k == 2 ? 0.53 : 0.0); comVel(k) = 0.05 * g.next(); }
         Twist tl, tr; for (int k = 0; k < 6; ++k) { tl(k) = 0.0; tr(k) = tick % 2 ? 0.2 * g.next() : 0.0; }
         if (tick == 3) for (int k = 0; k < 6; ++k) tl(k) = 0.1 * g.next();
+        // WalkingQPIK::setDesiredJointPosition at tick 4: the new posture must reach the solve
+        VectorDynSize reg(dof);
+        if (tick == 4) { for (int i = 0; i < dof; ++i) reg(i) = 0.2 * g.next(); if (!s->setDesiredJointPosition(reg)) return 3; }
         bool ok = s->setRobotState(q, lf, rf, neck, com);
         s->setDesiredNeckOrientation(neckDes); s->setDesiredFeetTransformation(lfd, rfd); s->setDesiredFeetTwist(tl, tr);
         s->setDesiredCoMVelocity(comVel); s->setDesiredCoMPosition(comDes);
@@ -116,6 +123,7 @@ static int run_ik(const char* ikIni, const char* form) {
         const bool gotTwice = got && s->getSolution(dq);
         WalkingQPIK_hip* h = osqp ? (WalkingQPIK_hip*)&so : (WalkingQPIK_hip*)&sq;
         std::printf("tick: %d %d %d %d %d %u %u\n", tick, (int)solved, (int)got, (int)gotTwice, h->status(), h->activeLower(), h->activeUpper());
+        if (tick == 4) line("q_reg", reg.data(), dof);
         line("J_left", JL.data(), 6 * n); line("J_right", JR.data(), 6 * n); line("J_neck6", JN.data(), 6 * n); line("J_com", JC.data(), 3 * n);
         line("q", q.data(), dof);
         line("p_left", lf.p.v, 3); line("R_left", lf.R.m, 9); line("p_right", rf.p.v, 3); line("R_right", rf.R.m, 9);

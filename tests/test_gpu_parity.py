@@ -148,8 +148,9 @@ def test_mpc_properties_at_full_size(wca):
 
 
 def test_hull_rows_from_foot_poses(wca, qs):
-    """§8f-3: device hull builder against the numpy builder of the synthetic workloads and the
+    """§8f-3: device hull builder against the oracle's builder (oracle/hull_spec.py) and the
     C++ host mirror's convention; then straight into the MPC kernel."""
+    from oracle import hull_spec as hs
     rng = np.random.default_rng(7)
     B = 300
     rect = np.array([0.05, 0.025, 0.05, -0.025, -0.02, -0.025, -0.02, 0.025])     # foot_size corners
@@ -163,12 +164,12 @@ def test_hull_rows_from_foot_poses(wca, qs):
     A, b, nc = wca.hull_from_feet_host(rect, pose(lxy, lyaw), pose(rxy, ryaw), contact)
     for i in range(B):
         pts = []
-        if contact[i] & 1: pts.append(wca.synth.foot_corners(lxy[i], lyaw[i]))
-        if contact[i] & 2: pts.append(wca.synth.foot_corners(rxy[i], ryaw[i]))
+        if contact[i] & 1: pts.append(hs.foot_corners(lxy[i], lyaw[i]))
+        if contact[i] & 2: pts.append(hs.foot_corners(rxy[i], ryaw[i]))
         if not pts:
             assert nc[i] == 0
             continue
-        Ar, br, ncr = wca.synth.hull_rows(np.vstack(pts))
+        Ar, br, ncr = hs.hull_rows(np.vstack(pts))
         assert nc[i] == ncr
         assert np.abs(A[i] - Ar).max() < 1e-12 and np.abs(b[i, :ncr] - br[:ncr]).max() < 1e-12 and (b[i, ncr:] == 1e30).all()
     # rows feed the MPC kernel unchanged
@@ -213,12 +214,15 @@ def test_ik_against_oracle_live(wca, qs, form, vmax, algorithm):
     p = qs.IKParams(v_max=vmax * np.ones(23))
     out = _ik_solver(wca, form, vmax, algorithm).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
     checked = 0
+    n_infeasible = 0
     for i in range(B):
         x = qs.ik_inputs_from_batch(b, i)
         try:
             r = qs.ik_exact(p, x, form)
         except qs.QPInfeasible:
-            assert out["status"][i] != wca.STATUS_SOLVED      # INFEASIBLE, or NUMERIC on a degenerate walk
+            # the dual active set says INFEASIBLE exactly when the oracle's phase-1 LP does: no NUMERIC / MAX_ITER here
+            assert out["status"][i] == wca.STATUS_INFEASIBLE
+            n_infeasible += 1
             continue
         assert out["status"][i] == wca.STATUS_SOLVED
         assert np.abs(out["dq"][i] - r["dq"]).max() <= SOL_TOL
@@ -227,6 +231,8 @@ def test_ik_against_oracle_live(wca, qs, form, vmax, algorithm):
             assert int(out["active_upper"][i]) == sum(1 << j for j in r["upper"])
         checked += 1
     assert checked > B * 0.8
+    if form == "qpoases" and vmax < 0.3:
+        assert n_infeasible >= 1                 # the tight variant really contains infeasible instances
 
 
 def test_ik_osqp_form_quirks(wca, qs):
@@ -331,6 +337,13 @@ def test_ik_properties_at_full_size(wca):
     out = s.solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
     ok = out["status"] == wca.STATUS_SOLVED
     assert ok.mean() > 0.999
+    # every instance the kernel did not solve must be infeasible for the exact oracle too
+    from oracle import qp_spec as qs
+    p_or = qs.IKParams(v_max=vmax * np.ones(23))
+    for i in np.flatnonzero(~ok):
+        assert out["status"][i] == wca.STATUS_INFEASIBLE
+        with pytest.raises(qs.QPInfeasible):
+            qs.ik_exact(p_or, qs.ik_inputs_from_batch(b, int(i)), "qpoases")
     dq = out["dq"]
     assert np.abs(dq[ok]).max() <= vmax + 1e-12                          # bounds hold
     lo, up = out["active_lower"], out["active_upper"]
@@ -383,3 +396,55 @@ def test_ik_kernels_agree_under_tight_bounds(wca, vmax):
         ok = ref["status"] == 0
         assert (o["active_lower"][ok] == ref["active_lower"][ok]).all() and (o["active_upper"][ok] == ref["active_upper"][ok]).all()
         assert np.abs(o["dq"][ok] - ref["dq"][ok]).max() <= 1e-9
+
+
+# ------------------------------------------------------------------ status paths ---
+def test_mpc_outside_hull_status(wca, qs):
+    """WalkingController::solve fails when computeMargin(u0) < -convex_hull_tolerance (cpp:513-517).  With a NEGATIVE
+    tolerance every solution closer than |tol| to the boundary - in particular every one ON it - must come back
+    WCQP_STATUS_OUTSIDE_HULL with the (rejected) optimum still in u0 (Appendix B-8); the others stay SOLVED."""
+    b = wca.synth.synth_mpc_batch(400, seed=77, uprev_sigma=0.06, x0_sigma=0.03)
+    tol = -0.004
+    strict = wca.MpcSolver(convex_hull_tolerance=tol).solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    plain = wca.MpcSolver().solve_host(b["x0"], b["ref"], b["u_prev"], b["hull_A"], b["hull_b"], b["hull_nc"])
+    assert (plain["status"] == wca.STATUS_SOLVED).all()
+    want_out = plain["margin"] < -tol
+    assert want_out.sum() > 20 and (~want_out).sum() > 20
+    assert (strict["status"][want_out] == wca.STATUS_OUTSIDE_HULL).all()
+    assert (strict["status"][~want_out] == wca.STATUS_SOLVED).all()
+    assert np.array_equal(strict["u0"], plain["u0"]) and (plain["active"][plain["margin"] < 1e-12] != 0).all()
+
+
+@pytest.mark.parametrize("algorithm", [0, 4, 3], ids=["default", "nullspace_16l", "nullspace_mfma"])
+def test_ik_max_iter_status(wca, algorithm):
+    """nWSR analogue (qp.cpp:312): with a budget of one working-set change, an instance that needs one bound is still
+    solved, one that needs more comes back WCQP_STATUS_MAX_ITER - never SOLVED with a violated bound."""
+    B, vmax = 600, 0.3
+    b = wca.synth.synth_ik_batch(B, seed=515)
+    args = (b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    full = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=algorithm).solve_host(*args)
+    one = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=algorithm, max_iter=1).solve_host(*args)
+    needs_more = (full["iters"] > 1) & (full["status"] == wca.STATUS_SOLVED)
+    needs_le1 = (full["iters"] <= 1) & (full["status"] == wca.STATUS_SOLVED)
+    assert needs_more.sum() > 20 and needs_le1.sum() > 20
+    assert (one["status"][needs_more] == wca.STATUS_MAX_ITER).all()
+    assert (one["status"][needs_le1] == wca.STATUS_SOLVED).all()
+    assert np.array_equal(one["dq"][needs_le1], full["dq"][needs_le1])
+
+
+def test_ik_posture_update_reaches_the_solve(wca, qs):
+    """wcqp_ik_set_posture = WalkingQPIK::setDesiredJointPosition: the new posture enters the gradient of the next solve
+    (osqp.cpp:185, qp.cpp:166)."""
+    B = 40
+    b = wca.synth.synth_ik_batch(B, seed=9)
+    args = (b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
+    s = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=2.0)
+    before = s.solve_host(*args)
+    reg = np.deg2rad(wca.synth.WALK_POSTURE_DEG)
+    s.set_posture(reg)
+    after = s.solve_host(*args)
+    assert np.abs(after["dq"] - before["dq"]).max() > 1e-2
+    p = qs.IKParams(v_max=2.0 * np.ones(23), joint_reg_deg=wca.synth.WALK_POSTURE_DEG.copy())
+    for i in range(0, B, 5):
+        r = qs.ik_exact(p, qs.ik_inputs_from_batch(b, i), "qpoases")
+        assert after["status"][i] == 0 and np.abs(after["dq"][i] - r["dq"]).max() <= SOL_TOL

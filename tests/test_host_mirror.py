@@ -85,11 +85,12 @@ def test_config_parsing_error_paths_and_hull_builder(tmp_path, wca):
     assert r["hull_none"][0] == 0                  # "None foot is in contact"
     assert r["output_before_solve"][0] == 0 and r["ik_solution_before_solve"][0] == 0   # one-shot guards
     # hull rows follow the same convention as the synthetic generator's numpy builder
+    from oracle import hull_spec as hs
     def feet(x, y, yaw):
-        return wca.synth.foot_corners(np.array([x, y]), yaw)
-    A, b, nc = wca.synth.hull_rows(np.vstack([feet(0.0, 0.08, 0.1), feet(0.05, -0.08, -0.05)]))
+        return hs.foot_corners(np.array([x, y]), yaw)
+    A, b, nc = hs.hull_rows(np.vstack([feet(0.0, 0.08, 0.1), feet(0.05, -0.08, -0.05)]))
     assert np.allclose(r["hull_ds_A"].reshape(-1, 2), A[:nc], atol=1e-14) and np.allclose(r["hull_ds_b"], b[:nc], atol=1e-14)
-    A1, b1, n1 = wca.synth.hull_rows(feet(0.0, 0.08, 0.1))
+    A1, b1, n1 = hs.hull_rows(feet(0.0, 0.08, 0.1))
     assert n1 == 4 and np.allclose(r["hull_ss_A"].reshape(-1, 2), A1[:4], atol=1e-14) and np.allclose(r["hull_ss_b"], b1[:4], atol=1e-14)
     assert r["margin"][0] == pytest.approx(np.min(b1[:4] - A1[:4] @ np.array([0.01, 0.08])), abs=1e-15)
 
@@ -106,9 +107,10 @@ def test_walking_controller_tick_sequence(tmp_path, qs):
     q_prev, feet_prev = None, None
     n_active = 0
     for r in recs:
-        tick, lc, rc, reset, solved, got, status, active = r["tick"].astype(int)
+        tick, lc, rc, reset, solved, got, status, active, did_reset = r["tick"].astype(int)
         feet = (lc, rc)
-        fresh = feet != feet_prev                  # new MPCSolver on contact change -> full rebuild
+        # new MPCSolver on contact change -> full rebuild; WalkingController::reset() (cpp:537-543) forces the same
+        fresh = feet != feet_prev or did_reset == 1
         feet_prev = feet
         dq = r["deque"].reshape(-1, 2)
         q = qs.mpc_gradient(c, dq, u_prev, q_prev=None if fresh else q_prev, reset=bool(reset))
@@ -122,6 +124,7 @@ def test_walking_controller_tick_sequence(tmp_path, qs):
         n_active += len(ex["active"])
         u_prev = r["u0"]
     assert n_active >= 1                           # tick 10 pushes the ZMP onto the hull
+    assert sum(int(r["tick"][8]) for r in recs) == 1          # reset() was exercised
 
 
 @pytest.mark.gpu
@@ -131,8 +134,11 @@ def test_walking_qpik_tick_sequence(tmp_path, qs, form):
     assert len(recs) == 6
     p = qs.IKParams(v_max=0.35 * np.ones(23))
     n_act = 0
+    saw_posture = False
     for r in recs:
         tick, solved, got, got_twice, status, lo, up = r["tick"].astype(int)
+        if "q_reg" in r:                           # setDesiredJointPosition: every later solve regularises to the new posture
+            p.joint_reg_deg = np.rad2deg(r["q_reg"]); saw_posture = True
         Rd_neck = r["neck_des_arg"].reshape(3, 3) @ p.additional_rotation       # setDesiredNeckOrientation
         x = qs.IKInputs(
             J_left=r["J_left"].reshape(6, 29), J_right=r["J_right"].reshape(6, 29),
@@ -151,5 +157,6 @@ def test_walking_qpik_tick_sequence(tmp_path, qs, form):
         if ex["mu_min_active"] > 1e-7 and ex["slack_min_inactive"] > 1e-7:
             assert int(lo) == sum(1 << j for j in ex["lower"]) and int(up) == sum(1 << j for j in ex["upper"])
         n_act += len(ex["lower"]) + len(ex["upper"])
+    assert saw_posture
     if form == "qpoases":
         assert n_act >= 1

@@ -102,3 +102,64 @@ def test_gpu_sharded_equals_single(wca):
         assert np.array_equal(np.concatenate([p["dq"] for p in parts_i]), one_i["dq"])
         assert np.array_equal(np.concatenate([p["active_upper"] for p in parts_i]), one_i["active_upper"])
         assert np.array_equal(np.concatenate([p["u0"] for p in parts_m]), one_m["u0"])
+
+
+def _gpu_worker(rank, world, port, exchange, q):
+    """One rank of the sharded HIP path: its own process, its own HIP context on the one GPU of the box, gloo for the
+    scatter / gather (what `nccl` = RCCL does between GPUs of a node)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import walking_controllers_amd as wca
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4)
+    mpc = wca.MpcSolver()
+    ki = ("J_left", "J_right", "J_neck", "J_com", "q", "state")
+    km = ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc")
+
+    def make(first, count):
+        bi = wca.synth.synth_ik_batch(count, seed=21, first=first)
+        bm = wca.synth.synth_mpc_batch(count, seed=22, first=first, uprev_sigma=0.04)
+        d = {k: bi[k] for k in ki}
+        d.update({k: (bm[k].astype(np.int64) if k == "hull_nc" else bm[k]) for k in km})
+        return d
+
+    def solve(inp):
+        oi = ik.solve_host(*[inp[k] for k in ki])
+        om = mpc.solve_host(*[(inp[k].astype(np.int32) if k == "hull_nc" else inp[k]) for k in km])
+        return {"dq": oi["dq"], "status": oi["status"].astype(np.int64), "up": oi["active_upper"].astype(np.int64),
+                "lo": oi["active_lower"].astype(np.int64), "u0": om["u0"], "mstatus": om["status"].astype(np.int64)}
+
+    out = wca.sharding.solve_sharded(dist, 512, make, solve, exchange=exchange)
+    if rank == 0:
+        q.put({k: v for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", [False, True])
+def test_two_ranks_on_the_gpu_match_single_process(wca, exchange):
+    """the N > 1 path with the HIP solver - two spawned ranks (fresh processes, no exec of a
+    GPU-initialised one) share the box's one GPU, rank 0 scatters the inputs and gathers the solutions over gloo
+    (`exchange`), or every rank generates its own block; the gathered result is bitwise the single-process solve."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, exchange, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    bi = wca.synth.synth_ik_batch(512, seed=21)
+    bm = wca.synth.synth_mpc_batch(512, seed=22, uprev_sigma=0.04)
+    oi = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4).solve_host(bi["J_left"], bi["J_right"], bi["J_neck"], bi["J_com"], bi["q"], bi["state"])
+    om = wca.MpcSolver().solve_host(bm["x0"], bm["ref"], bm["u_prev"], bm["hull_A"], bm["hull_b"], bm["hull_nc"])
+    assert np.array_equal(got["dq"], oi["dq"]) and np.array_equal(got["status"], oi["status"])           # bitwise
+    assert np.array_equal(got["up"], oi["active_upper"]) and np.array_equal(got["lo"], oi["active_lower"])
+    assert np.array_equal(got["u0"], om["u0"]) and np.array_equal(got["mstatus"], om["status"])

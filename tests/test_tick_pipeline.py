@@ -71,6 +71,14 @@ def test_tick_pipeline_long_run_is_stable_and_shard_invariant(wca):
     full = run(d, 0, B)
     assert full["tick"] == T and full["mpc_fail"].sum() == 0
     assert full["ik_fail"].sum() <= 0.001 * B * T
+    # an IK the device did not solve must be one the exact oracle cannot solve either:
+    # replay every failing robot (at most three) through oracle/tick_spec.py and compare the failure counts
+    from oracle import tick_spec as ts, qp_spec as qs
+    for i in np.flatnonzero(full["ik_fail"])[:3]:
+        one = {k: (v[i:i + 1] if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+        one["first"] = int(i)
+        ref = ts.run_ticks(ts.TickParams(), one, T, qs.IKParams(v_max=0.5 * np.ones(23)))
+        assert ref["ik_fail"][0] == full["ik_fail"][i]
     assert np.abs(full["dcm"] - d["ref_traj"][:, T]).max() < 0.05
     halves = [run(wca.synth.synth_tick_batch(B // 2, T, first=f), f, B // 2) for f in (0, B // 2)]
     assert np.array_equal(np.concatenate([h["q_des"] for h in halves]), full["q_des"])

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "wcqp_strerror", "wcqp_version", "wcqp_device_count",
     "wcqp_mpc_create", "wcqp_mpc_destroy", "wcqp_mpc_get_condensed", "wcqp_mpc_get_matrices",
     "wcqp_mpc_solve_device", "wcqp_mpc_solve_host",
-    "wcqp_ik_create", "wcqp_ik_destroy", "wcqp_ik_solve_device", "wcqp_ik_solve_host",
+    "wcqp_ik_create", "wcqp_ik_destroy", "wcqp_ik_set_posture", "wcqp_ik_solve_device", "wcqp_ik_solve_host",
     "wcqp_hull_from_feet_device", "wcqp_hull_from_feet_host",
     "wcqp_kin_create", "wcqp_kin_destroy", "wcqp_kin_jacobians_device", "wcqp_kin_jacobians_host",
     "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download",
@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
         L.wcqp_mpc_solve_host.argtypes = mpc_args
         L.wcqp_ik_create.argtypes = [C.POINTER(IkParams), C.POINTER(C.c_void_p)]
         L.wcqp_ik_destroy.argtypes = [C.c_void_p]
+        L.wcqp_ik_set_posture.argtypes = [C.c_void_p, C.c_void_p]
         ik_args = [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp, dp, ip, up, up, dp, ip]
         L.wcqp_ik_solve_device.argtypes = ik_args + [vp]
         L.wcqp_ik_solve_host.argtypes = ik_args
@@ -239,6 +240,11 @@ class IkSolver:
             self.close()
         except Exception:
             pass
+
+    def set_posture(self, joint_reg_rad):
+        """WalkingQPIK::setDesiredJointPosition: a new regularisation posture (rad) for every later solve."""
+        a = _f64(np.asarray(joint_reg_rad, float).reshape(self.dof))
+        check(lib().wcqp_ik_set_posture(self._h, _p(a)), "wcqp_ik_set_posture")
 
     def solve_host(self, J_left, J_right, J_neck, J_com, q, state, want_foot_err=True):
         J_left, J_right, J_neck, J_com, q, state = map(_f64, (J_left, J_right, J_neck, J_com, q, state))

@@ -332,6 +332,8 @@ bool WalkingQPIK::setNeckJacobian(const MatrixDynSize& J) {
 bool WalkingQPIK::setDesiredJointPosition(const VectorDynSize& regularizationTerm) {
     if ((int)regularizationTerm.size() != m_actuatedDOFs) { std::fprintf(stderr, "[setDesiredJointPosition] The number of the desired joint position has to be equal to the number of actuated joints\n"); return false; }
     m_regularizationTerm = regularizationTerm;
+    // the posture enters the gradient of every solve (osqp.cpp:185, qp.cpp:166): hand it to the solver handle
+    if (!pushPosture()) return false;
     return true;
 }
 void WalkingQPIK::setDesiredFeetTransformation(const Transform& l, const Transform& r) { m_desiredLeftFootToWorldTransform = l; m_desiredRightFootToWorldTransform = r; }
@@ -377,10 +379,22 @@ bool WalkingQPIK_hip::initialize(const Searchable& config, const int& actuatedDO
         p.v_min[i] = minJointsLimit(i); p.v_max[i] = maxJointsLimit(i);
     }
     p.k_pos_com = m_kCom; p.k_pos_foot = m_kPosFoot; p.k_att_foot = m_kAttFoot; p.k_neck = m_kNeck;
+    // the caller of these classes hands over iDynTree free-floating Jacobians in MIXED representation
+    // (WalkingForwardKinematics.cpp:33, 436-454); anything else still works (general kernel behind the check)
+    p.jacobian_structure = WCQP_IK_JAC_AUTO;
     if (m_handle) { wcqp_ik_destroy(m_handle); m_handle = nullptr; }
     const int rc = wcqp_ik_create(&p, &m_handle);
     if (rc != WCQP_OK) { std::fprintf(stderr, "[initialize] %s\n", wcqp_strerror(rc)); return false; }
     m_solution.assign(m_actuatedDOFs, 0.0); m_footErr.assign(12, 0.0);
+    return true;
+}
+
+bool WalkingQPIK_hip::pushPosture() {
+    if (!m_handle) return true;                       // before initialize(): picked up when the handle is created
+    std::vector<double> q(m_actuatedDOFs);
+    for (int i = 0; i < m_actuatedDOFs; ++i) q[i] = m_regularizationTerm(i);
+    const int rc = wcqp_ik_set_posture(m_handle, q.data());
+    if (rc != WCQP_OK) { std::fprintf(stderr, "[setDesiredJointPosition] %s\n", wcqp_strerror(rc)); return false; }
     return true;
 }
 

@@ -83,6 +83,7 @@ protected:
     bool m_isSolutionEvaluated{false};
     bool m_useCoMAsConstraint{false};
     virtual bool initializeMatrices(const Searchable& config);
+    virtual bool pushPosture() { return true; }      // back-end hook of setDesiredJointPosition
 public:
     virtual ~WalkingQPIK();
     virtual bool initialize(const Searchable& config, const int& actuatedDOFs,
@@ -118,6 +119,7 @@ public:
     ~WalkingQPIK_hip() override;
     bool initialize(const Searchable& config, const int& actuatedDOFs,
                     const VectorDynSize& minJointsLimit, const VectorDynSize& maxJointsLimit) final;
+    bool pushPosture() final;
     bool solve() final;
     bool getSolution(VectorDynSize& output) final;
     bool getLeftFootError(VectorDynSize& output) final;

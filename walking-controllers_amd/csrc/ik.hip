@@ -507,6 +507,16 @@ int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out) {
     return WCQP_OK;
 }
 
+int wcqp_ik_set_posture(wcqp_ik_t h, const double* joint_reg_rad) {
+    if (!h || !joint_reg_rad) return WCQP_E_INVALID;
+    for (int j = 0; j < kDof; ++j) { h->p.joint_reg_rad[j] = joint_reg_rad[j]; h->hp.qreg[6 + j] = joint_reg_rad[j]; }
+    if (h->d_prm) {
+        WCQP_HIP_TRY(hipDeviceSynchronize());
+        WCQP_HIP_TRY(hipMemcpy(h->d_prm, &h->hp, sizeof(IkDeviceParams), hipMemcpyHostToDevice));
+    }
+    return WCQP_OK;
+}
+
 int wcqp_ik_destroy(wcqp_ik_t h) {
     if (!h) return WCQP_E_INVALID;
     if (h->d_prm) (void)hipFree(h->d_prm);
