@@ -152,7 +152,7 @@ int wcqp_hull_from_feet_host(int32_t batch, const double* foot_rect,
  * ===================================================================================== */
 #define WCQP_IK_FORM_QPOASES 0   /* bounds enforced, kappa = 1, feet always corrected        */
 #define WCQP_IK_ALG_DEFAULT   0
-#define WCQP_IK_ALG_SWEEP     1
+#define WCQP_IK_ALG_SWEEP     1        /* round-1 A/B baseline; diagnostic builds only (-DWCQP_DIAG_KERNELS), else WCQP_E_UNSUPPORTED */
 #define WCQP_IK_ALG_NULLSPACE 2        /* null-space kernel, reduced Hessian on the fp64 VALU                 */
 #define WCQP_IK_ALG_NULLSPACE_MFMA 3   /* same, reduced-Hessian Gram product as one v_mfma_f64_16x16x4 tile per
                                           instance: ~5 % faster than 2 in interleaved A/B runs;

@@ -27,9 +27,12 @@
 #include <new>
 #include "ik_common.h"
 
+// The sweep kernel below is the round-1 A/B baseline: compiled only into diagnostic builds (-DWCQP_DIAG_KERNELS,
+// tools/build_variant.sh); the product library carries ik4 (default), ik3 (general fall-back) and ik2 (CoM as cost).
+using namespace wcqp_ik;
+#ifdef WCQP_DIAG_KERNELS
 namespace {
 
-using namespace wcqp_ik;
 
 constexpr int kLD = 30;                // leading dim of 29-wide LDS rows: even (16-B aligned b128
                                        // broadcasts) and 60 dwords mod 64 -> at most 2-way on row-per-lane reads
@@ -404,6 +407,7 @@ void ik_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 }
 
 }  // namespace
+#endif  // WCQP_DIAG_KERNELS
 
 // ======================================================================================
 struct wcqp_ik_s {
@@ -442,6 +446,9 @@ int wcqp_ik_create(const wcqp_ik_params* params, wcqp_ik_t* out) {
     if (params->dof != kDof) return WCQP_E_UNSUPPORTED;      // kernels are unrolled for iCub's 23 DoF
     if (params->form != WCQP_IK_FORM_QPOASES && params->form != WCQP_IK_FORM_OSQP) return WCQP_E_INVALID;
     if (params->algorithm < 0 || params->algorithm > WCQP_IK_ALG_BASE_ELIM) return WCQP_E_INVALID;
+#ifndef WCQP_DIAG_KERNELS
+    if (params->algorithm == WCQP_IK_ALG_SWEEP) return WCQP_E_UNSUPPORTED;      // diagnostic builds only
+#endif
     if (params->jacobian_structure < WCQP_IK_JAC_AUTO || params->jacobian_structure > WCQP_IK_JAC_GENERAL) return WCQP_E_INVALID;
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < r; ++c)          // the kernels use W J and J'W interchangeably: symmetric weights only
@@ -552,6 +559,7 @@ int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
     if (h->p.algorithm != WCQP_IK_ALG_SWEEP)
         return wcqp_ik::ik2_launch(h->d_prm, h->p.use_com_as_constraint != 0, h->p.algorithm != WCQP_IK_ALG_NULLSPACE, batch, J_left, J_right, J_neck, J_com,
                                    q, state, dq, status, active_lower, active_upper, foot_err, iters, (hipStream_t)stream);
+#ifdef WCQP_DIAG_KERNELS
     const unsigned grid = (unsigned)((batch + 1) / 2);
     if (h->p.use_com_as_constraint)
         hipLaunchKernelGGL(ik_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream,
@@ -563,6 +571,9 @@ int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
                            dq, status, active_lower, active_upper, foot_err, iters);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
+#else
+    return WCQP_E_UNSUPPORTED;            // refused at create already
+#endif
 }
 
 int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
