@@ -64,6 +64,7 @@ def main():
                          "instances (one more, nearly empty, launch), general = the general kernel only")
     ap.add_argument("--tick-tables", action="store_true", help="tick workload: constant uploaded Jacobians and precomputed hull tables "
                     "(round-1 form) instead of per-tick kinematics")
+    ap.add_argument("--tick-cold-ik", action="store_true", help="tick workload: no IK hot start (every tick walks the active set from the unconstrained optimum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     args = ap.parse_args()
@@ -361,7 +362,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     (constant uploaded Jacobians, precomputed hull tables; one launch per tick)."""
     T = args.steps + args.warmup
     kin_mode = not args.tick_tables
-    vmax = args.ik_vmax if args.tick_tables else max(args.ik_vmax, 1.0)     # the walking robot needs ~1 rad/s (DESIGN.md)
+    vmax = args.ik_vmax if args.tick_tables else max(args.ik_vmax, 1.5)     # the walking robot needs ~1 rad/s of joint velocity (DESIGN.md)
     # `--streams 2`: the batch is cut into two independent halves, each its own pipeline on its own HIP stream.
     # Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
     n_streams = args.streams if args.streams else (2 if B >= 8192 and B % 2 == 0 else 1)
@@ -378,7 +379,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
         else:
             data = wca.synth.synth_tick_batch(cnt, T, first=f0)
             iks = wca.IkSolver(form=ik_form, v_max=vmax)
-        pp = wca.TickPipeline(cnt, T, wca.MpcSolver(horizon=50), iks, first=f0, kin=kin)
+        pp = wca.TickPipeline(cnt, T, wca.MpcSolver(horizon=50), iks, first=f0, kin=kin, ik_hot_start=not args.tick_cold_ik)
         pp.upload(data)
         pipes.append(pp)
     stream = torch.cuda.current_stream(dev)
@@ -409,7 +410,8 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     elapsed = max_over_ranks(dist, torch, dev, elapsed)
     states = [pp.download() for pp in pipes]
     out_state = {"tick": min(x["tick"] for x in states), "mpc_fail": np.concatenate([x["mpc_fail"] for x in states]),
-                 "ik_fail": np.concatenate([x["ik_fail"] for x in states])}
+                 "ik_fail": np.concatenate([x["ik_fail"] for x in states]),
+                 "hot_try": int(sum(x["hot_try"].sum() for x in states)), "hot_hit": int(sum(x["hot_hit"].sum() for x in states))}
     dev_ms = e0.elapsed_time(e1) / args.steps
     value = 2 * B * world * args.steps / elapsed
     # algorithmic I/O of a tick (6296 B) + resident controller / plant state read and written; with per-tick
@@ -434,7 +436,10 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "avg_launch_ms": dev_ms, "algorithmic_bytes_per_launch": bytes_per_tick * B},
         "solved": {"ticks_executed": out_state["tick"], "mpc_fail": int(out_state["mpc_fail"].sum()),
-                   "ik_fail": int(out_state["ik_fail"].sum()), "robots_with_ik_fail": int((out_state["ik_fail"] > 0).sum()), "of": B * T},
+                   "ik_fail": int(out_state["ik_fail"].sum()), "robots_with_ik_fail": int((out_state["ik_fail"] > 0).sum()), "of": B * T,
+                   # IK hot start: robot-ticks on which the previous tick's active bounds were tried first / accepted
+                   "ik_hot_start_tried": out_state["hot_try"], "ik_hot_start_accepted": out_state["hot_hit"],
+                   "ik_hot_start_hit_rate": (out_state["hot_hit"] / out_state["hot_try"]) if out_state["hot_try"] else None},
     }
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -328,6 +328,11 @@ typedef struct wcqp_tick_params {
      * support-polygon rows from the DESIRED foot poses (state0 entries 24..47, `foot_rect`) whenever an instance's
      * contact pair changes (setConvexHullConstraint, ...PredictiveController.cpp:364-435).  Two launches per tick
      * (kinematics, solve).  The J_* and hull_tab_* inputs are then ignored (may be NULL). */
+    /* IK hot start (SQProblem::hotstart, WM/src/WalkingQPInverseKinematics_qpOASES.cpp:312-335): by default every tick
+     * first tries the previous tick's active joint-velocity bounds of the robot (added in one step, accepted when all
+     * their multipliers are positive) and falls back to the cold active-set walk otherwise; 1 = always cold.
+     * Same optimum either way (the QP is strictly convex); base-eliminated kernel only. */
+    int32_t ik_cold_start_only;
     int32_t use_kinematics;
     wcqp_kin_params kin;
     double  foot_rect[8];       /* corners (x, y) x 4 of the foot rectangle in the foot frame (foot_size, cpp:295-303) */
@@ -352,6 +357,7 @@ typedef struct wcqp_tick_outputs {  /* HOST pointers, any may be NULL */
     double* q_des;              /* [B][dof]                                                    */
     double* dcm; double* com;   /* [B][2]                                                      */
     int64_t* mpc_fail; int64_t* ik_fail;   /* [B] ticks whose QP did not end SOLVED            */
+    int64_t* hot_try; int64_t* hot_hit;    /* [B] ticks on which the previous active set was tried / accepted (IK hot start) */
     int32_t* tick;              /* ticks executed so far                                       */
 } wcqp_tick_outputs;
 

@@ -131,7 +131,11 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const int col1 = j + 16;
 
     int tick_now = 0;
-    if constexpr (TICK) tick_now = td.tick2[td.phase];
+    unsigned prev_lo = 0u, prev_up = 0u;            // hot start: the previous tick's active bounds of this instance
+    if constexpr (TICK) {
+        tick_now = td.tick2[td.phase];
+        if (td.hot_start && alo_out && aup_out) { prev_lo = alo_out[inst]; prev_up = aup_out[inst]; }
+    }
 
     WCQP_STAMP(0);
     // ---------------- phase 0: loads ------------------------------------------------------------
@@ -522,8 +526,122 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             mu_p = 0.0;
             pending = true;
         };
+        // ---- hot start (tick pipeline): the previous tick's active bounds, ADDED IN ONE STEP.  With W0 = {(p_a, sigma_a)},
+        // k0 <= KS bounds: columns tau_a = P e_{p_a} (one LDS round trip for all of them), R = N' P N (k0 x k0, entries by
+        // ds_bpermute), multipliers mu = R^-1 s with s_a = sigma_a (x_{p_a} - bound_a), x <- x - sum mu_a sigma_a tau_a.
+        // If every mu_a > 0 this is exactly the state the dual active set reaches after adding these bounds one by one
+        // without a drop (an S-pair), so the walk continues from it - usually straight to "no violated bound".
+        // Otherwise (a previous bound no longer wants to be active, a dependent set) the attempt is discarded and
+        // the cold walk starts from the unconstrained optimum: the fall-back SQProblem::hotstart makes implicitly.
+        bool warm_done = false;
+        if constexpr (TICK) {
+            const unsigned pm = prev_lo | prev_up;
+            const int k0 = __popc(pm);
+            if (k0 >= 1 && k0 <= KS) {
+                double* yp4 = S + OFF_YPV;                     // [KS][16]: YPV, RV, CV, ROWB are free until the general loop
+                unsigned m = pm;
+                double sgW[KS];
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    const int pa = m ? __ffs(m) - 1 : 0;
+                    sgW[a] = m ? (((prev_up >> pa) & 1u) ? 1.0 : -1.0) : 0.0;
+                    wS[a] = pa;
+                    m &= m - 1u;
+                }
+                wcqp::wave_lds_fence();
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    const double* colp = S + OFF_CT + wS[a] * LDC;
+                    double t = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NR; r += 2) { const double2 c2 = ld2(colp + r); t = fma(Hr[r], c2.x, t); t = fma(Hr[r + 1], c2.y, t); }
+                    yp4[a * 16 + j] = j < NR ? t : 0.0;
+                }
+                wcqp::wave_lds_fence();
+                double ua0[KS], ua1[KS];
+#pragma unroll
+                for (int a = 0; a < KS; ++a) { ua0[a] = (wS[a] == j) ? 1.0 : 0.0; ua1[a] = (wS[a] == col1) ? 1.0 : 0.0; }
+#pragma unroll
+                for (int r = 0; r < NR; r += 2) {
+                    const double2 a2 = ld2(ct0 + r), b2 = ld2(ct1 + r);
+#pragma unroll
+                    for (int a = 0; a < KS; ++a) {
+                        const double2 y2 = ld2(yp4 + a * 16 + r);
+                        ua0[a] = fma(a2.x, y2.x, ua0[a]); ua0[a] = fma(a2.y, y2.y, ua0[a]);
+                        ua1[a] = fma(b2.x, y2.x, ua1[a]); ua1[a] = fma(b2.y, y2.y, ua1[a]);
+                    }
+                }
+                double Rm[KS][KS], Ri[KS][KS], sv[KS];
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    const double w0 = sgW[a] * ua0[a], w1 = var1 ? sgW[a] * ua1[a] : 0.0;     // signed column of bound a on the own variables
+                    tc0[a] = w0; tc1[a] = w1;
+                }
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    const bool used = sgW[a] != 0.0;
+#pragma unroll
+                    for (int b = 0; b < KS; ++b) {
+                        const double g = at_var(tc0[b], tc1[b], wS[a]);               // sigma_b P[p_a][p_b]
+                        Rm[a][b] = (used && sgW[b] != 0.0) ? sgW[a] * g : (a == b ? 1.0 : 0.0);
+                        Ri[a][b] = a == b ? 1.0 : 0.0;
+                    }
+                    const double xa = at_var(nu0, nu1, wS[a]);
+                    const double ba = sgW[a] > 0.0 ? at_var(hi0, hi1, wS[a]) : at_var(lo0, lo1, wS[a]);
+                    sv[a] = used ? sgW[a] * (xa - ba) : 0.0;
+                }
+                bool okw = true;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {                 // Gauss-Jordan, no pivoting: R is SPD when the set is independent
+                    const double piv = Rm[k][k];
+                    okw = okw && piv > 1e-12;
+                    const double ip = wcqp::fast_rcp(piv);
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) { Rm[k][c] *= ip; Ri[k][c] *= ip; }
+#pragma unroll
+                    for (int i2 = 0; i2 < KS; ++i2) {
+                        if (i2 == k) continue;
+                        const double f = Rm[i2][k];
+#pragma unroll
+                        for (int c = 0; c < KS; ++c) { Rm[i2][c] = fma(-f, Rm[k][c], Rm[i2][c]); Ri[i2][c] = fma(-f, Ri[k][c], Ri[i2][c]); }
+                    }
+                }
+                double muW[KS];
+#pragma unroll
+                for (int a = 0; a < KS; ++a) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int b = 0; b < KS; ++b) acc = fma(Ri[a][b], sv[b], acc);
+                    muW[a] = acc;
+                    okw = okw && (sgW[a] == 0.0 || acc > 0.0);
+                }
+                if (live && j == 0) td.hot_try[inst] += 1;
+                if (okw) {
+#pragma unroll
+                    for (int a = 0; a < KS; ++a) {
+                        const bool used = sgW[a] != 0.0;
+                        nu0 = fma(-muW[a], tc0[a], nu0);                 // muW = 0 on unused slots
+                        nu1 = fma(-muW[a], tc1[a], nu1);
+                        sgS[a] = sgW[a]; muS[a] = used ? muW[a] : 0.0;
+#pragma unroll
+                        for (int b = a; b < KS; ++b) Rs[a][b] = (used && sgW[b] != 0.0) ? Ri[a][b] : 0.0;
+                        if (used && wS[a] == j) { in_w0 = true; sig0 = sgW[a]; }
+                        if (used && wS[a] == col1) { in_w1 = true; sig1 = sgW[a]; }
+                    }
+                    nW = k0;
+                    pending = false;
+                    warm_done = true;
+                    wcqp::wave_lds_fence();
+                    done = most_violated() == 0u;
+                    if (live && j == 0) td.hot_hit[inst] += 1;
+                } else {
+#pragma unroll
+                    for (int a = 0; a < KS; ++a) { wS[a] = 0; tc0[a] = 0.0; tc1[a] = 0.0; }
+                }
+            }
+        }
         // First bound, empty working set, straight-line: full step along tau_p, the bound takes slot 0.
-        {
+        if (!warm_done) {
             const unsigned key = most_violated();          // != 0: that is what `need` said
             enter(key, true);
             if (ppp > 0.0) {

@@ -148,6 +148,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
     // the tick's Jacobians are MIXED free-floating ones (uploaded or from wcqp_kin_*): an instance that is not comes
     // back WCQP_STATUS_STRUCTURE and counts as an IK failure
+    h->d.hot_start = params->ik_cold_start_only ? 0 : 1;
     h->base_elim = h->fused && params->ik.algorithm != WCQP_IK_ALG_NULLSPACE_16L &&
                    params->ik.jacobian_structure != WCQP_IK_JAC_GENERAL && wcqp::ik_fast_ok(h->ik);
     const size_t B = (size_t)params->batch;
@@ -171,6 +172,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     A_(d.q_des, B * kDof); A_(d.dq_prev, B * kDof); A_(d.dq, B * kDof);
     A_(d.sel, B);
     A_(d.state, B * kStateLen); A_(d.mpc_status, B); A_(d.ik_status, B); A_(d.mpc_fail, B); A_(d.ik_fail, B);
+    A_(d.hot_try, B); A_(d.hot_hit, B);
     A_(d.tick2, 2); A_(d.u0_log, (size_t)d.log_ticks * B * 2); A_(d.dq_log, (size_t)d.log_ticks * B * kDof);
     A_(h->J_left, B * 6 * 29); A_(h->J_right, B * 6 * 29); A_(h->J_neck, B * 3 * 29); A_(h->J_com, B * 3 * 29);
     A_(h->mpc_active, B); A_(h->mpc_margin, B); A_(h->ik_lo, B); A_(h->ik_up, B);
@@ -239,6 +241,8 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
         WCQP_HIP_TRY(hipMemcpy(d.sel, sel.data(), B * 4, hipMemcpyHostToDevice));
     }
     WCQP_HIP_TRY(hipMemset(d.mpc_fail, 0, B * 8)); WCQP_HIP_TRY(hipMemset(d.ik_fail, 0, B * 8));
+    WCQP_HIP_TRY(hipMemset(d.hot_try, 0, B * 8)); WCQP_HIP_TRY(hipMemset(d.hot_hit, 0, B * 8));
+    WCQP_HIP_TRY(hipMemset(h->ik_lo, 0, B * 4)); WCQP_HIP_TRY(hipMemset(h->ik_up, 0, B * 4));      // no previous active set at tick 0
     h->uploaded = true;
     h->ticks_enqueued = 0;
     return WCQP_OK;
@@ -290,7 +294,8 @@ int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
 #define DN_(dst, src, n) if (dst) WCQP_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
     DN_(out->u0_log, d.u0_log, (size_t)d.log_ticks * B * 16); DN_(out->dq_log, d.dq_log, (size_t)d.log_ticks * B * kDof * 8);
     DN_(out->q_des, d.q_des, B * kDof * 8); DN_(out->dcm, d.dcm, B * 16); DN_(out->com, d.com, B * 16);
-    DN_(out->mpc_fail, d.mpc_fail, B * 8); DN_(out->ik_fail, d.ik_fail, B * 8); DN_(out->tick, d.tick2 + (h->ticks_enqueued & 1), 4);
+    DN_(out->mpc_fail, d.mpc_fail, B * 8); DN_(out->ik_fail, d.ik_fail, B * 8);
+    DN_(out->hot_try, d.hot_try, B * 8); DN_(out->hot_hit, d.hot_hit, B * 8); DN_(out->tick, d.tick2 + (h->ticks_enqueued & 1), 4);
 #undef DN_
     return WCQP_OK;
 }

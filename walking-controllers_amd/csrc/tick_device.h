@@ -39,6 +39,10 @@ struct TickDev {
     // instance's initial one
     int kin_mode;
     const double* com_h0;     // [B]
+    // IK hot start (qpOASES SQProblem::hotstart, WM/src/WalkingQPInverseKinematics_qpOASES.cpp:316-318): the previous
+    // tick's active bounds (the kernel's own active_lower / active_upper words, 8 B per robot) are tried first
+    int hot_start;
+    long long *hot_try, *hot_hit;     // [B] ticks on which a previous active set was tried / accepted
 };
 
 // Per-tick kinematics (wcqp_tick_params::use_kinematics): what the kinematics kernel needs beyond the model when it

@@ -404,8 +404,8 @@ def synth_kin_batch(count: int, seed: int = 31415, first: int = 0, joint_sigma: 
 
 def synth_walk_kin_batch(count: int, first: int = 0) -> dict:
     """Base poses / joint angles the walk scenario starts from: robots standing upright on the tree's own crouch
-    (WALK_POSTURE_DEG), a few degrees of scatter."""
-    return synth_kin_batch(count, seed=27182, first=first, joint_sigma=0.03, posture_deg=WALK_POSTURE_DEG, base_rot_sigma=0.03)
+    (WALK_POSTURE_DEG), a degree of scatter (a stance wider than ~14 cm over-stretches the far leg when the pelvis sways over one foot)."""
+    return synth_kin_batch(count, seed=27182, first=first, joint_sigma=0.015, posture_deg=WALK_POSTURE_DEG, base_rot_sigma=0.015)
 
 
 def synth_walk_batch(count: int, n_ticks: int, poses: np.ndarray, kin_batch: dict, seed: int = 2718, horizon: int = 50,
