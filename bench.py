@@ -362,7 +362,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     (constant uploaded Jacobians, precomputed hull tables; one launch per tick)."""
     T = args.steps + args.warmup
     kin_mode = not args.tick_tables
-    vmax = args.ik_vmax if args.tick_tables else max(args.ik_vmax, 1.5)     # the walking robot needs ~1 rad/s of joint velocity (DESIGN.md)
+    vmax = args.ik_vmax if args.tick_tables else max(args.ik_vmax, 1.0)     # the walking robot needs up to ~1 rad/s of joint velocity (DESIGN.md)
     # `--streams 2`: the batch is cut into two independent halves, each its own pipeline on its own HIP stream.
     # Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
     n_streams = args.streams if args.streams else (2 if B >= 8192 and B % 2 == 0 else 1)

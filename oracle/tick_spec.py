@@ -162,8 +162,15 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
                 s[69:71] = p_star[i]; s[71] = p.com_height
             s[72:74] = v_star[i]; s[74] = 0.0
             k = int(code[i])
-            s[75:81] = 0.0 if k in (0, 2) else data["swing_twist"][i]      # left foot in contact -> zero twist
-            s[81:87] = 0.0 if k in (1, 2) else data["swing_twist"][i]
+            tw = data["swing_twist"][i]
+            if use_kin:
+                # the swing foot's velocity profile over its single-support phase: zero net displacement (tick_device.h)
+                sidx = ((t + int(data["phase0"][i])) % (2 * p.step_ticks)) % p.step_ticks
+                ss = p.step_ticks - p.ds_ticks
+                x = (sidx - p.ds_ticks) / float(ss) if sidx >= p.ds_ticks else 0.0
+                tw = tw * (10.392304845413264 * x * (1.0 - x) * (1.0 - 2.0 * x) if sidx >= p.ds_ticks else 0.0)
+            s[75:81] = 0.0 if k in (0, 2) else tw      # left foot in contact -> zero twist
+            s[81:87] = 0.0 if k in (1, 2) else tw
             Jsrc = {n: J_now[i][n][None] for n in ("J_left", "J_right", "J_neck", "J_com")} if use_kin else \
                    {n: data[n][i:i + 1] for n in ("J_left", "J_right", "J_neck", "J_com")}
             one = dict(q=q_des[i:i + 1], state=s[None, :], **Jsrc)

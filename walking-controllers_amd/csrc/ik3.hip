@@ -159,7 +159,7 @@ void ik3_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const int mst = td.mpc_status[i_];
                 const bool mpc_ok = mst == WCQP_STATUS_SOLVED || mst == WCQP_STATUS_OUTSIDE_HULL;
                 if (j < 2) wcqp_tick::tick_glue_axis(td, i_, tick_now, j, mpc_ok, td.u0[2 * i_ + j], g_com, g_pstar, g_vel);
-                if (j < 6) wcqp_tick::tick_glue_twist(td, i_, td.sel[i_], j, g_twl, g_twr);
+                if (j < 6) wcqp_tick::tick_glue_twist(td, i_, td.sel[i_], j, tick_now, g_twl, g_twr);
                 if (j == 0 && !mpc_ok) td.mpc_fail[i_] += 1;
             }
         }

@@ -36,7 +36,7 @@ __global__ void tick_glue_kernel(TickDev d) {
         if (!d.kin_mode) s[66 + ax] = g_com;
     }
     tick_glue_height(d, i, s);
-    for (int k = 0; k < 6; ++k) tick_glue_twist(d, i, code, k, s[75 + k], s[81 + k]);
+    for (int k = 0; k < 6; ++k) tick_glue_twist(d, i, code, k, t, s[75 + k], s[81 + k]);
 }
 
 __global__ void tick_post_kernel(TickDev d) {

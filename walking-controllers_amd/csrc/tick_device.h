@@ -118,9 +118,21 @@ __device__ __forceinline__ void tick_glue_axis(const TickDev& d, int i, int t, i
     d.u_prev[2 * i + ax] = u;
     if (t < d.log_ticks) d.u0_log[((size_t)t * d.batch + i) * 2 + ax] = u;
 }
+// velocity profile of the swing foot over its single-support phase x in [0, 1): f(x) = 6 sqrt(3) x (1 - x)(1 - 2x), peak 1,
+// zero integral - the foot leaves its planted pose by at most 0.325 * amplitude * T_ss and is back at touch-down
+// (kinematics mode only: with real kinematics a twist held constant for the whole swing drags the foot out of the
+// leg's reach; the constant-Jacobian mode keeps the round-1 constant twist)
+__device__ __forceinline__ double swing_profile(const TickDev& d, int i, int t) {
+    if (!d.kin_mode) return 1.0;
+    const int sidx = ((t + d.phase0[i]) % (2 * d.step_ticks)) % d.step_ticks;
+    const int ss = d.step_ticks - d.ds_ticks;
+    if (sidx < d.ds_ticks || ss < 1) return 0.0;
+    const double x = (double)(sidx - d.ds_ticks) / (double)ss;
+    return 10.392304845413264 * x * (1.0 - x) * (1.0 - 2.0 * x);
+}
 // component k of the two desired foot twists: a foot in contact keeps a zero twist
-__device__ __forceinline__ void tick_glue_twist(const TickDev& d, int i, int code, int k, double& tw_left, double& tw_right) {
-    const double tw = d.swing_twist[(size_t)i * 6 + k];
+__device__ __forceinline__ void tick_glue_twist(const TickDev& d, int i, int code, int k, int t, double& tw_left, double& tw_right) {
+    const double tw = d.swing_twist[(size_t)i * 6 + k] * swing_profile(d, i, t);
     tw_left = (code == 0 || code == 2) ? 0.0 : tw;      // -> state[75 + k]
     tw_right = (code == 1 || code == 2) ? 0.0 : tw;     // -> state[81 + k]
 }

@@ -425,7 +425,7 @@ def synth_walk_batch(count: int, n_ticks: int, poses: np.ndarray, kin_batch: dic
     u_ph = rng.uniform(2)
     phase0 = ((u_ph[:, 0] < 0.5) * step_ticks + (0.35 + 0.2 * u_ph[:, 1]) * ds_ticks).astype(np.int32)
     dcm_n = rng.normal(2, 0.002)
-    swing = rng.normal(6, 0.08)        # a leg of ~0.45 m turns 0.2 m/s into ~0.5 rad/s: keep the swing foot slow
+    swing = rng.normal(6, 0.05)        # amplitude of the swing foot's twist profile (zero net displacement: tick_device.h)
     neck_w = rng.normal(3, 0.02)
     state0 = np.array(poses, dtype=np.float64, copy=True)
     for src, dst, k in (("p_left", "pd_left", 3), ("R_left", "Rd_left", 9), ("p_right", "pd_right", 3), ("R_right", "Rd_right", 9)):
