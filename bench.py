@@ -57,6 +57,7 @@ def main():
                     help="qp workload: 2 = the (independent) MPC and IK batches go to two HIP streams and may overlap; "
                          "0 = auto: 2 up to 32768 robots per GPU (+18 %% at 4096, +18 %% at 8192, +9 %% at 16384, +2 %% at 32768: the MPC "
                          "kernel fits beside the IK kernel), 1 above (at 65536 the overlap slows the IK kernel more than it saves)")
+    ap.add_argument("--horizon", type=int, default=50, help="qp workload: MPC horizon N (BASELINE: 50; the shipped controllerHorizon 2 s is N = 200: auxiliary line)")
     ap.add_argument("--input-sets", type=int, default=0, help="qp workload: distinct input sets visited round-robin (0 = enough for > 320 MB, at least 2)")
     ap.add_argument("--ik-jac", choices=["mixed", "auto", "general"], default="mixed",
                     help="wcqp_ik_params.jacobian_structure: mixed = the caller states what the reference always passes (iDynTree MIXED "
@@ -99,7 +100,9 @@ def main():
         return bench_kin(args, wca, torch, dist, dev, world, rank, B, first)
     # ---- synthetic inputs (each rank generates its own shard: identical to the rows a rank-0
     # scatter would hand it, walking-controllers_amd/synth.py is counter-based) -------------
-    mb = wca.synth.synth_mpc_batch(B, seed=1234, first=first)
+    NH = args.horizon
+    mpc_bytes = 8 * (2 + 2 * (NH + 1) + 2 + 24) + 16          # x0, reference window, u_prev, padded hull in; u0 out (1056 B at N = 50)
+    mb = wca.synth.synth_mpc_batch(B, seed=1234, first=first, horizon=NH)
     ib = wca.synth.synth_ik_batch(B, seed=4321, first=first)
 
     def up(a, dtype=None):
@@ -112,7 +115,7 @@ def main():
     # K input sets in distinct HBM allocations, visited round-robin, so that every launch reads COLD inputs: one set is
     # 6.1 KB x B (25 MB at 4096 robots) and would otherwise sit in the 256 MiB Infinity Cache from the previous step.
     # Set k is the same batch rotated by k B / K instances: same work per launch, different bytes at every address.
-    set_bytes = B * (MPC_BYTES_PER_QP - 16 + IK_BYTES_PER_QP - 184)
+    set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
     K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
     u0 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
@@ -125,7 +128,7 @@ def main():
     iup = torch.zeros(B, dtype=torch.int32, device=dev)
     iit = torch.zeros(B, dtype=torch.int32, device=dev)
 
-    mpc = wca.MpcSolver(horizon=50)
+    mpc = wca.MpcSolver(horizon=NH)
     ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
     jac = {"mixed": wca.IK_JAC_MIXED, "auto": wca.IK_JAC_AUTO, "general": wca.IK_JAC_GENERAL}[args.ik_jac]
     ik = wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=jac)
@@ -246,10 +249,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[1]+[2] per GPU: DCM-MPC QP (N=50, n=202, cold start) B=%d + QP-IK "
+            "workload": ("BASELINE configs[1]+[2] per GPU: DCM-MPC QP (N=%d, n=%d, cold start) B=%d + QP-IK "
                          "(iCub 23 DoF, 15 eq rows, %s form, v_max=%.2f rad/s) B=%d; 2 QP solves per robot-tick"
-                         % (B, args.ik_form, args.ik_vmax, B)),
-            "batch_per_gpu": B, "global_batch": B * world, "horizon": 50, "dof": 23,
+                         % (NH, 4 * NH + 2, B, args.ik_form, args.ik_vmax, B)),
+            "batch_per_gpu": B, "global_batch": B * world, "horizon": NH, "dof": 23,
             "input_sets": K, "input_bytes_per_set": set_bytes, "ik_jacobian_structure": args.ik_jac,
             "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ""),
         },
@@ -270,7 +273,7 @@ def main():
             "ik_mfma_f64_tflops": 12288.0 * B / (ik_ms * 1e-3) / 1e12, "ik_mfma_f64_frac": 12288.0 * B / (ik_ms * 1e-3) / 78.6e12,
             "ik_auto_ms": ik_auto_ms, "ik_auto_fallback_launch_ms": ik_auto_ms - ik_ms,
             "mpc_ms": mpc_ms, "mpc_ms_resident_inputs": mpc_ms_res, "mpc_qps_per_gpu": B / (mpc_ms * 1e-3),
-            "mpc_hbm_frac": MPC_BYTES_PER_QP * B / (mpc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "mpc_hbm_frac": mpc_bytes * B / (mpc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mpc_bytes_per_qp": mpc_bytes,
         },
         "solved": {"ik": n_ok_ik, "mpc": n_ok_mpc, "of": B, "ik_mean_active_set_changes": ik_iters,
                    "ik_frac_with_active_bounds": frac_active},

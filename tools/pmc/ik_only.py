@@ -9,7 +9,7 @@ ib = wca.synth.synth_ik_batch(B, seed=4321)
 d = {k: torch.from_numpy(ib[k]).to(dev) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")}
 dq = torch.zeros(B, 23, dtype=torch.float64, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
 sp = torch.cuda.current_stream().cuda_stream
-ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=alg)
+ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=alg, jacobian_structure=wca.IK_JAC_MIXED)
 for _ in range(12):
     ik.solve_device(B, d["J_left"].data_ptr(), d["J_right"].data_ptr(), d["J_neck"].data_ptr(), d["J_com"].data_ptr(),
                     d["q"].data_ptr(), d["state"].data_ptr(), dq.data_ptr(), st.data_ptr(), 0, 0, 0, 0, sp)
