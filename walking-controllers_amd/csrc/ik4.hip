@@ -180,6 +180,9 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 if (j == 0 && !mpc_ok) td.mpc_fail[i_] += 1;
             }
         }
+        // the state / q loads above must ISSUE before the 36 column loads (vmcnt retires in order): hipcc otherwise sinks
+        // one of them below the Jacobian loads and the state's LDS stores then wait for everything (vmcnt(0))
+        __builtin_amdgcn_sched_barrier(0);
         const int fc0 = 6 + j;
         const int fc1 = var1 ? 22 + j : (base1 ? j - 8 : 0);
         const double* jl = JL + inst * (6 * kNV);
@@ -194,9 +197,10 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         for (int r = 0; r < 3; ++r) { a0[12 + r] = jc[r * kNV + fc0]; a1[12 + r] = jc[r * kNV + fc1]; }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { a0[15 + r] = jn[r * kNV + fc0]; a1[15 + r] = jn[r * kNV + fc1]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 5; ++m) st[m * 16 + j] = sreg[m];
-        if (80 + j < kStateLen) st[80 + j] = sreg[5];
+        st[80 + j] = sreg[5];        // unconditional (slots 87..95 are spare): a predicated store makes hipcc sink the LOAD into the branch, behind the column loads
         if constexpr (TICK) {
             wcqp::wave_lds_fence();
             if (j < 2) { if (!td.kin_mode) st[66 + j] = g_com; st[69 + j] = g_pstar; st[72 + j] = g_vel; }
@@ -363,34 +367,55 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     const double tol = prm->tol;
     const int max_iter = prm->max_iter;
     double lo0 = prm->vlo[v0i] * isd0, hi0 = prm->vhi[v0i] * isd0, lo1 = prm->vlo[v1i] * isd1, hi1 = prm->vhi[v1i] * isd1;
-    // ---------------- phase 5: sweep over the 12 pivots (no search: M is SPD), y, x~ ----------------------
+    // ---------------- phase 5: sweep over the 12 pivots in 2 x 2 BLOCKS (no search: M is SPD), y, x~ ------------
+    // A block step publishes two columns and applies the rank-2 update with the block's explicit inverse (computed
+    // redundantly by every lane from the published entries): the same FMAs and LDS traffic as two single pivots, but
+    // ONE LDS write -> read round trip per two pivots - the phase is a latency chain, not an issue problem.
     bool ok = true;
     {
-        double* col = S + OFF_COL;
+        double* col = S + OFF_COL;          // [2][2][16]: double-buffered pair of columns: all of region B (YV is written after the sweep, DV is dead by now)
+        static_assert(OFF_DV + 16 == OFF_COL + 64, "the column pairs take the 64 doubles of region B");
         double pmin = 1.0;
         col[j] = Hr[0];
+        col[16 + j] = Hr[1];
         wcqp::wave_lds_fence();
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            double* cb = col + 16 * (k & 1);
-            double* nb = col + 16 * ((k + 1) & 1);
-            const double piv = cb[k];
-            pmin = (piv > 0.0) ? pmin : -1.0;
-            const double d = wcqp::fast_rcp(piv);
-            const double f0 = Hr[k] * d;
-            const double f = (j == k) ? (1.0 - d) : f0;
-            if (k + 1 < NR) {
-                Hr[k + 1] = fma(-f, cb[k + 1], Hr[k + 1]);
-                nb[j] = Hr[k + 1];                        // publish the next column early
-            }
+        for (int k = 0; k < NR; k += 2) {
+            const int buf = (k >> 1) & 1;
+            const double* cA = col + 32 * buf;          // column k
+            const double* cB = cA + 16;                 // column k + 1
+            double ca[NR + 2], cb2[NR + 2];
 #pragma unroll
             for (int q = 0; q <= NR; q += 2) {
-                const double2 c2 = ld2(cb + q);
-                if (q != k && !(q == k + 1 && k + 1 < NR)) Hr[q] = fma(-f, c2.x, Hr[q]);
-                if (q + 1 <= NR && q + 1 != k && !(q + 1 == k + 1 && k + 1 < NR)) Hr[q + 1] = fma(-f, c2.y, Hr[q + 1]);
+                const double2 x2 = ld2(cA + q), y2 = ld2(cB + q);
+                ca[q] = x2.x; ca[q + 1] = x2.y; cb2[q] = y2.x; cb2[q + 1] = y2.y;
             }
-            Hr[k] = (j == k) ? -d : f0;
-            // hipcc otherwise defers the updates of several pivots (their factors stay alive: +100 VGPRs)
+            const double pa = ca[k], pb = ca[k + 1], pd = cb2[k + 1];
+            const double det = fma(pa, pd, -pb * pb);
+            pmin = (pa > 0.0 && det > 0.0) ? pmin : -1.0;
+            const double idet = wcqp::fast_rcp(det);
+            const double i11 = pd * idet, i12 = -pb * idet, i22 = pa * idet;
+            const double m1 = Hr[k], m2 = Hr[k + 1];
+            const double g1 = fma(m1, i11, m2 * i12), g2 = fma(m1, i12, m2 * i22);     // rows other than k, k + 1
+            const bool isk = j == k, isk1 = j == k + 1;
+            const double f1 = isk ? 1.0 - i11 : (isk1 ? -i12 : g1);
+            const double f2 = isk ? -i12 : (isk1 ? 1.0 - i22 : g2);
+            if (k + 2 < NR) {
+                Hr[k + 2] = fma(-f2, cb2[k + 2], fma(-f1, ca[k + 2], Hr[k + 2]));
+                Hr[k + 3] = fma(-f2, cb2[k + 3], fma(-f1, ca[k + 3], Hr[k + 3]));
+                double* nb = col + 32 * (buf ^ 1);
+                nb[j] = Hr[k + 2];                        // publish the next pair early
+                nb[16 + j] = Hr[k + 3];
+            }
+#pragma unroll
+            for (int q = 0; q <= NR; ++q) {
+                if (q == k || q == k + 1) continue;
+                if (k + 2 < NR && (q == k + 2 || q == k + 3)) continue;
+                Hr[q] = fma(-f2, cb2[q], fma(-f1, ca[q], Hr[q]));
+            }
+            Hr[k] = isk ? -i11 : (isk1 ? -i12 : g1);
+            Hr[k + 1] = isk ? -i12 : (isk1 ? -i22 : g2);
+            // hipcc otherwise defers the updates of several steps (their factors stay alive: +100 VGPRs)
 #pragma unroll
             for (int q = 0; q <= NR; ++q) __asm__ volatile("" : "+v"(Hr[q]));
             wcqp::wave_lds_fence();
