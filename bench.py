@@ -135,7 +135,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
     n_streams = args.streams if args.streams else (2 if B <= 32768 else 1)
-    two_streams = n_streams == 2 and not (args.exchange and world > 1)
+    two_streams = n_streams == 2
     stream_mpc = torch.cuda.Stream(dev) if two_streams else stream
     sp_mpc = stream_mpc.cuda_stream
     N1 = mb["ref"].shape[1]
@@ -178,9 +178,11 @@ def main():
         d = sets[0] if exch else sets[i % K]
         if exch:
             exch[0]()
+            stream_mpc.wait_stream(stream)          # the MPC stream starts behind the scatter ...
         launch_mpc(d)
         launch_ik(d)
         if exch:
+            stream.wait_stream(stream_mpc)          # ... and the gather behind both solves: the two batches still overlap
             exch[1]()
 
     def barrier():
