@@ -513,7 +513,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         };
         // makes the bound of `key` the pending one: p, sig, s, signed column tau_p, P[p][p]; `replicated`: also
         // tau_p at the variables of the replicated working set
-        auto enter = [&](unsigned key, bool replicated) {
+        auto enter = [&](unsigned key, int KG) {                          // replicated slots 0 .. KG-1 may be live (KG wave-uniform)
             ++it;
             p = 31 - (int)(key & 31u);
             const bool sl1 = p >= 16;
@@ -543,9 +543,9 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             }
             u1 = var1 ? u1 : 0.0;
             ppp = lane_gather(sl1 ? u1 : u0, src);                       // P[p][p] > 0
-            if (replicated) {
 #pragma unroll
-                for (int a = 0; a < KS; ++a) tvS[a] = at_var(u0, u1, wS[a]);
+            for (int a = 0; a < KS; ++a) {
+                if (a < KG) tvS[a] = at_var(u0, u1, wS[a]);
             }
             tp0 = sig * u0; tp1 = sig * u1;
             mu_p = 0.0;
@@ -559,6 +559,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         // Otherwise (a previous bound no longer wants to be active, a dependent set) the attempt is discarded and
         // the cold walk starts from the unconstrained optimum: the fall-back SQProblem::hotstart makes implicitly.
         bool warm_done = false;
+        unsigned key = 0u;                              // the violated bound to take up next (0: none left)
         if constexpr (TICK) {
             const unsigned pm = prev_lo | prev_up;
             const int k0 = __popc(pm);
@@ -657,7 +658,8 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                     pending = false;
                     warm_done = true;
                     wcqp::wave_lds_fence();
-                    done = most_violated() == 0u;
+                    key = most_violated();
+                    done = key == 0u;
                     if (live && j == 0) td.hot_hit[inst] += 1;
                 } else {
 #pragma unroll
@@ -667,8 +669,8 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         }
         // First bound, empty working set, straight-line: full step along tau_p, the bound takes slot 0.
         if (!warm_done) {
-            const unsigned key = most_violated();          // != 0: that is what `need` said
-            enter(key, true);
+            key = most_violated();                         // != 0: that is what `need` said
+            enter(key, 0);
             if (ppp > 0.0) {
                 const double inz = wcqp::fast_rcp(ppp);
                 const double t = s * inz;
@@ -680,40 +682,43 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 if (p == col1) { in_w1 = true; sig1 = sig; }
                 nW = 1;
                 pending = false;
-                done = most_violated() == 0u;
+                key = most_violated();
+                done = key == 0u;
             } else {
                 st_code = WCQP_STATUS_INFEASIBLE; done = true;
             }
         }
         bool small = !done;
+        // The replicated loop.  A pass is issue-bound (a wave is alone on its SIMD at the BASELINE batch) and most working
+        // sets hold one or two bounds, so the per-slot work is skipped - with wave-uniform branches - for the slots above
+        // the highest live one over the instances of the wave that are still walking (Kw; an entering bound may take
+        // slot Kw).  Skipped slots would have contributed exact zeros: results do not depend on Kw.
 #pragma unroll 1
         for (int pass = 0; pass < 1024 && small; ++pass) {
+            const int Kw = __ballot(sgS[3] != 0.0) != 0ull ? 4 : __ballot(sgS[2] != 0.0) != 0ull ? 3 : __ballot(sgS[1] != 0.0) != 0ull ? 2 : 1;
             if (!pending) {
                 if (nW >= KS) { small = false; break; }                      // a fifth bound: general loop
-                const unsigned key = most_violated();
-                if (key == 0u) { done = true; small = false; break; }
                 if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; small = false; break; }
-                enter(key, true);
+                enter(key, Kw);
             }
             double c[KS], r[KS];
 #pragma unroll
-            for (int a = 0; a < KS; ++a) c[a] = sgS[a] * sig * tvS[a];       // 0 on slots that are not live
+            for (int a = 0; a < KS; ++a) { c[a] = sgS[a] * sig * tvS[a]; r[a] = 0.0; }       // 0 on slots that are not live
             double z0 = tp0, z1 = tp1, nzv = ppp, t1 = inf;
             int jd = 0;
 #pragma unroll
             for (int a = 0; a < KS; ++a) {
-                double ra = 0.0;
+                if (a < Kw) {
+                    double ra = 0.0;
 #pragma unroll
-                for (int b = 0; b < KS; ++b) ra = fma(b >= a ? Rs[a][b] : Rs[b][a], c[b], ra);
-                r[a] = ra;
-                z0 = fma(-ra, tc0[a], z0);
-                z1 = fma(-ra, tc1[a], z1);
-                nzv = fma(-ra, c[a], nzv);
-            }
-#pragma unroll
-            for (int a = 0; a < KS; ++a) {
-                const double ratio = (sgS[a] != 0.0 && r[a] > 0.0) ? muS[a] * wcqp::fast_rcp(r[a]) : inf;
-                if (ratio < t1) { t1 = ratio; jd = a; }                      // ties: lowest slot
+                    for (int b = 0; b < KS; ++b) ra = fma(b >= a ? Rs[a][b] : Rs[b][a], c[b], ra);
+                    r[a] = ra;
+                    z0 = fma(-ra, tc0[a], z0);
+                    z1 = fma(-ra, tc1[a], z1);
+                    nzv = fma(-ra, c[a], nzv);
+                    const double ratio = (sgS[a] != 0.0 && ra > 0.0) ? muS[a] * wcqp::fast_rcp(ra) : inf;
+                    if (ratio < t1) { t1 = ratio; jd = a; }                  // ties: lowest slot
+                }
             }
             const double inz = wcqp::fast_rcp(nzv);
             const double t2 = (nzv > 1e-10 * ppp) ? s * inz : inf;           // dependence shows as a vanishing Schur complement
@@ -731,23 +736,27 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 for (int a = KS - 1; a >= 0; --a) n = (sgS[a] != 0.0) ? n : a;
 #pragma unroll
                 for (int a = 0; a < KS; ++a) {
-                    const bool me = a == n;
-                    const double ra_inz = r[a] * inz;
+                    if (a <= Kw) {
+                        const bool me = a == n;
+                        const double ra_inz = r[a] * inz;
 #pragma unroll
-                    for (int b = a; b < KS; ++b) {
-                        const double upd = fma(ra_inz, r[b], Rs[a][b]);
-                        Rs[a][b] = (b == n) ? (me ? inz : -ra_inz) : (me ? -r[b] * inz : upd);
+                        for (int b = a; b < KS; ++b) {
+                            const double upd = fma(ra_inz, r[b], Rs[a][b]);
+                            Rs[a][b] = (b == n) ? (me ? inz : -ra_inz) : (me ? -r[b] * inz : upd);
+                        }
+                        wS[a] = me ? p : wS[a];
+                        sgS[a] = me ? sig : sgS[a];
+                        muS[a] = me ? mu_p : muS[a];
+                        tc0[a] = me ? tp0 : tc0[a];
+                        tc1[a] = me ? tp1 : tc1[a];
                     }
-                    wS[a] = me ? p : wS[a];
-                    sgS[a] = me ? sig : sgS[a];
-                    muS[a] = me ? mu_p : muS[a];
-                    tc0[a] = me ? tp0 : tc0[a];
-                    tc1[a] = me ? tp1 : tc1[a];
                 }
                 if (p == j) { in_w0 = true; sig0 = sig; }
                 if (p == col1) { in_w1 = true; sig1 = sig; }
                 ++nW;
                 pending = false;
+                key = most_violated();
+                if (key == 0u) { done = true; small = false; }
             } else {
                 int wdrop = 0;
                 double cj[KS];
@@ -803,10 +812,10 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll 1
             for (int pass = 0; pass < 1024 && !done; ++pass) {
                 if (!pending) {
-                    const unsigned key = most_violated();
+                    key = most_violated();
                     if (key == 0u) { done = true; }
                     else if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; }
-                    else enter(key, false);
+                    else enter(key, 0);
                 }
                 if (!done) {
                     // dual step r = Rinv c,  c_a = sigma_a tau_p[w_a]  (tau_p at the slot's variable: both slots of
