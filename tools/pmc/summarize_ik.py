@@ -1,6 +1,7 @@
 """Per-launch means of the IK-only PMC passes (tools/pmc/collect_ik.sh)."""
 import csv, glob, json, os, sys, collections
 root = sys.argv[1]
+NAMES = tuple(sys.argv[2:]) or ("ik4_kernel", "ik3_kernel", "ik2_kernel", "ik_kernel")
 res = collections.defaultdict(dict)
 for d in sorted(os.listdir(root)):
     if not os.path.isdir(os.path.join(root, d)): continue
@@ -8,7 +9,7 @@ for d in sorted(os.listdir(root)):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(root, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if any(n in r["Kernel_Name"] for n in ("ik4_kernel", "ik3_kernel", "ik2_kernel", "ik_kernel")):
+            if any(n in r["Kernel_Name"] for n in NAMES):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c, v in acc.items():
         v = v[2:] if len(v) > 4 else v

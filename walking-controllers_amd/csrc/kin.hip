@@ -11,8 +11,9 @@
 // checked against is oracle/kin_spec.py (itself pinned by differentiating its forward kinematics).
 //
 // Layout: 32 lanes per instance (two per wave64); lane i owns COLUMN i of every Jacobian (0..5 base,
-// 6 + j joint j), so every output row is one coalesced 232-byte segment.  The tree is walked level by
-// level (parent[j] < j, depth <= 8): a joint's world frame needs its parent's, through LDS.
+// 6 + j joint j), so every output row is one coalesced 232-byte segment.  The tree is composed by pointer
+// jumping through LDS (ceil(log2 depth) rounds in which every joint lane works), subtree first moments are
+// differences of a prefix sum over the lanes when the joint numbering is depth-first.
 // HBM-bound by its output: 280 B in, 4464 B out per instance.
 #include <cmath>
 #include <cstring>
@@ -27,9 +28,12 @@ namespace {
 constexpr int kMaxDof = WCQP_KIN_MAX_DOF;     // 32
 constexpr int kStateLen = WCQP_IK_STATE_LEN;
 
+constexpr int kMaxRounds = 5;                 // pointer jumping covers 2^5 = 32 >= kMaxDof levels
+
 struct KinDev {
-    int dof, max_level;
-    int parent[kMaxDof], level[kMaxDof];
+    int dof, n_rounds, dfs_contig;
+    int up[kMaxRounds][kMaxDof];              // up[0] = parent, up[r + 1][j] = up[r][up[r][j]] (-1: above the root)
+    int sub_end[kMaxDof];                     // last joint of j's subtree when the subtrees are index ranges (dfs_contig)
     unsigned desc_mask[kMaxDof];              // joints moved by joint j (itself included)
     unsigned path_mask[3];                    // joints on the path root -> frame f
     double R0[kMaxDof][9], p0[kMaxDof][3], axis[kMaxDof][3], mass[kMaxDof], com[kMaxDof][3];
@@ -51,19 +55,66 @@ __device__ __forceinline__ void mat3_vec(const double* A, const double* v, doubl
 __device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
     o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
 }
+// (Ro, po) = (Ra, pa) o (Rb, pb)
+__device__ __forceinline__ void frame_mul(const double* Ra, const double* pa, const double* Rb, const double* pb, double* Ro, double* po) {
+    mat3_mul(Ra, Rb, Ro);
+    double d[3];
+    mat3_vec(Ra, pb, d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) po[k] = pa[k] + d[k];
+}
+// lane i of a DPP row receives lane i - N (0 below the row start)
+template <int N>
+__device__ __forceinline__ double row_shr0(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over each 32-lane half of the wave: four shifts inside the 16-lane DPP rows, then lane 15 / 47
+// goes to every lane of the row above it (row_bcast:15 into rows 1 and 3)
+__device__ __forceinline__ double half_scan(double v) {
+    v += row_shr0<1>(v);
+    v += row_shr0<2>(v);
+    v += row_shr0<4>(v);
+    v += row_shr0<8>(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xa, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xa, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
 
-// LDS per instance (doubles): Tw [32][12] world frame of every joint, MC [33][4] {m c, m} per link
-// (slot 32 = root link), FR [3][12] attached frames, CT [4] total first moment / mass
-constexpr int OFF_TW = 0, OFF_MC = 32 * 12, OFF_FR = OFF_MC + 33 * 4, OFF_CT = OFF_FR + 36, PER_INST = OFF_CT + 4;
+// LDS per instance (doubles): TW [32][12] every joint's frame (base coordinates) while the tree is composed; afterwards
+// the same space holds PS [32][4] prefix sums of {m c, m} over the joints (or MC [33][4] for tables whose subtrees are not
+// index ranges); FRB [3][12] attached frames in base coordinates, FR [3][12] the same in world coordinates; SD [24] the
+// pose input (base pose, or the desired poses of the two soles in the tick pipeline)
+constexpr int OFF_TW = 0, OFF_PS = 0, OFF_MC = 128, OFF_FR = 32 * 12, OFF_FRB = OFF_FR + 36, OFF_SD = OFF_FRB + 36, PER_INST = OFF_SD + 24;
+static_assert(OFF_MC + 33 * 4 <= OFF_FR, "the first moments overlay the joint frames");
 
-// TICK: the tick pipeline's per-tick call (WalkingModule.cpp:715, 396-410): base pose from the plant, support-polygon
+#ifdef WCQP_KIN_STAMPS
+// diagnostic build: s_memtime at the phase boundaries, written through kt.hull_b (stand-alone launches only)
+#define WCQP_KSTAMP(k) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+                            if (lane == 0 && kt.hull_b) reinterpret_cast<unsigned long long*>(kt.hull_b)[(size_t)blockIdx.x * 8 + (k)] = t__; } while (0)
+#else
+#define WCQP_KSTAMP(k) do { } while (0)
+#endif
+
+// small model facts as kernel arguments: no load in front of the first address computation
+struct KinShape { int dof, n_rounds, dfs_contig; };
+
+// TICK: the tick pipeline's per-tick call (WalkingModule.cpp:715, 396-410): base pose from the stance foot, support-polygon
 // rows rebuilt on a contact change (tick_device.h: KinTick)
+//
+// The kernel is a LATENCY chain per wave (3-4 waves per SIMD, each about a thousand instructions between two trips to
+// memory), so every global load is issued at the top, in the order of use: q and the joint's constants, the
+// pointer-jumping links, the pose input (one element per lane, handed round through LDS), the link and frame constants.
+#ifndef WCQP_KIN_WAVES
+#define WCQP_KIN_WAVES 4                       // waves per SIMD the register budget is set for
+#endif
 template <bool TICK>
-__global__ __launch_bounds__(64)
-void kin_jacobians_kernel(const KinDev* __restrict__ md, int batch,
+__global__ __launch_bounds__(64, WCQP_KIN_WAVES)
+void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch,
                           const double* __restrict__ base, const double* __restrict__ q,
                           double* __restrict__ JL, double* __restrict__ JR, double* __restrict__ JN, double* __restrict__ JC,
-                          double* __restrict__ state, wcqp_tick::KinTick kt)
+                          double* state, wcqp_tick::KinTick kt)
 {
     __shared__ __attribute__((aligned(16))) double smem[2][PER_INST];
     const int lane = threadIdx.x, half = lane >> 5, i = lane & 31;
@@ -71,196 +122,234 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, int batch,
     const bool live = inst_raw < batch;
     const long inst = live ? inst_raw : (long)batch - 1;
     double* S = smem[half];
-    const int dof = md->dof;
+    const int dof = shp.dof;
     const int j = i - 6;                                   // joint of this lane's column
     const bool is_joint = j >= 0 && j < dof;
     const int jc = is_joint ? j : 0;
 
-    // base pose
-    double pb[3], Rb[9];
-    {
-        if constexpr (TICK) {
-            // the tree is walked in base coordinates first; the base pose follows from the anchor foot below
+    WCQP_KSTAMP(0);
+    // ---------------- every global load of the kernel ------------------------------------------------------
+    const double qj = q[inst * dof + jc];
+    double R0[9], pa[3], ax[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pb[k] = 0.0;
+    for (int k = 0; k < 9; ++k) R0[k] = md->R0[jc][k];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Rb[k] = (k % 4 == 0) ? 1.0 : 0.0;
-        } else {
-            const double* b = base + inst * 12;
+    for (int k = 0; k < 3; ++k) { ax[k] = md->axis[jc][k]; pa[k] = md->p0[jc][k]; }
+    int up[kMaxRounds];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pb[k] = b[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Rb[k] = b[3 + k];
-        }
+    for (int r = 0; r < kMaxRounds; ++r) up[r] = md->up[r][jc];
+    double pose_in = 0.0;
+    int side = 0;
+    if constexpr (TICK) {
+        if (i < 24) pose_in = state[inst * kStateLen + 24 + i];                  // desired poses of the two soles: p (3), R (9) each
+        const int t_now = kt.tick2[kt.phase];
+        side = ((t_now + kt.phase0[inst]) % (2 * kt.step_ticks)) / kt.step_ticks;     // 0: left is the stance foot
+    } else {
+        if (i < 12) pose_in = base[inst * 12 + i];
     }
-    // own joint: local rotation R0 * Rot(axis, q)   (Rodrigues)
-    double Rloc[9], p0[3], ax[3];
-    const int par = md->parent[jc], lvl = is_joint ? md->level[jc] : 0;
+    double cj[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cj[k] = md->com[jc][k];
+    const double mj = md->mass[jc];
+    const int sub_end = md->sub_end[jc];
+    const int fi = i < 3 ? i : 0;
+    const int jfi = md->frame_joint[fi];
+    double fR[9], fp[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) fR[k] = md->frame_R[fi][k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fp[k] = md->frame_p[fi][k];
+
+    unsigned on_path = 0u;                                 // bit f: this lane's joint is on the path root -> frame f
+#pragma unroll
+    for (int f = 0; f < 3; ++f) on_path |= ((md->path_mask[f] >> jc) & 1u) << f;
+    if (!is_joint) on_path = 0u;
+    double rootc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rootc[k] = md->root_com[k];
+    const double root_mass = md->root_mass;
+
+    if (i < 24) S[OFF_SD + i] = pose_in;
+    WCQP_KSTAMP(1);
+    // own joint: local frame (R0 * Rot(axis, q), p0) relative to the parent's   (Rodrigues)
+    double Ra[9];
     {
-        const double qj = q[inst * dof + jc];
         double sn, cs;
         sincos(qj, &sn, &cs);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { ax[k] = md->axis[jc][k]; p0[k] = md->p0[jc][k]; }
         const double v = 1.0 - cs;
         const double Rq[9] = {cs + v * ax[0] * ax[0],         v * ax[0] * ax[1] - sn * ax[2], v * ax[0] * ax[2] + sn * ax[1],
                               v * ax[1] * ax[0] + sn * ax[2], cs + v * ax[1] * ax[1],         v * ax[1] * ax[2] - sn * ax[0],
                               v * ax[2] * ax[0] - sn * ax[1], v * ax[2] * ax[1] + sn * ax[0], cs + v * ax[2] * ax[2]};
-        double R0[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) R0[k] = md->R0[jc][k];
-        mat3_mul(R0, Rq, Rloc);
+        mat3_mul(R0, Rq, Ra);
     }
-    // world frames, level by level
-    double Rw[9], pw[3];
+    WCQP_KSTAMP(2);
+    // the tree, in base coordinates, by POINTER JUMPING: after round r the lane's frame is relative to its 2^(r+1)-th
+    // ancestor (every joint lane works in every round; a level-by-level walk runs the same code once per tree level
+    // for the three or four lanes of that level)
+    double* Tm = S + OFF_TW + jc * 12;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Rw[k] = 0.0;
+    for (int r = 0; r < kMaxRounds; ++r) {
+        if (r >= shp.n_rounds) break;
+        if (is_joint) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pw[k] = 0.0;
-    const int max_level = md->max_level;
-    for (int L = 1; L <= max_level; ++L) {
-        if (lvl == L) {
-            double Rp[9], pp[3];
-            if (par < 0) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) Rp[k] = Rb[k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) pp[k] = pb[k];
-            } else {
-                const double* T = S + OFF_TW + par * 12;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) Rp[k] = T[k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) pp[k] = T[9 + k];
-            }
-            mat3_mul(Rp, Rloc, Rw);
-            double d[3];
-            mat3_vec(Rp, p0, d);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) pw[k] = pp[k] + d[k];
-            double* T = S + OFF_TW + j * 12;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) T[k] = Rw[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) T[9 + k] = pw[k];
+            for (int k = 0; k < 8; k += 2) *reinterpret_cast<double2*>(Tm + k) = make_double2(Ra[k], Ra[k + 1]);
+            *reinterpret_cast<double2*>(Tm + 8) = make_double2(Ra[8], pa[0]);
+            *reinterpret_cast<double2*>(Tm + 10) = make_double2(pa[1], pa[2]);
         }
         wcqp::wave_lds_fence();
+        const int u = up[r];
+        if (is_joint && u >= 0) {
+            const double* T = S + OFF_TW + u * 12;
+            double Rp[9], pp[3], Rn[9], pn[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rp[k] = T[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pp[k] = T[9 + k];
+            frame_mul(Rp, pp, Ra, pa, Rn, pn);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Ra[k] = Rn[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pa[k] = pn[k];
+        }
+        wcqp::wave_lds_fence();               // every lane has read: the frames may be overwritten
     }
+    if (is_joint) {
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) *reinterpret_cast<double2*>(Tm + k) = make_double2(Ra[k], Ra[k + 1]);
+        *reinterpret_cast<double2*>(Tm + 8) = make_double2(Ra[8], pa[0]);
+        *reinterpret_cast<double2*>(Tm + 10) = make_double2(pa[1], pa[2]);
+    }
+    wcqp::wave_lds_fence();
+    // attached frames (lanes 0..2), base coordinates
+    WCQP_KSTAMP(3);
+    double Rf[9], pf[3];
+    {
+        const double* T = S + OFF_TW + jfi * 12;
+        double Rj[9], pj[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rj[k] = T[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pj[k] = T[9 + k];
+        frame_mul(Rj, pj, fR, fp, Rf, pf);
+        if (i < 3) {
+            double* F = S + OFF_FRB + i * 12;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) F[k] = Rf[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) F[9 + k] = pf[k];
+        }
+    }
+    wcqp::wave_lds_fence();
+    // base pose
+    double pb[3], Rb[9];
     if constexpr (TICK) {
-        // anchor foot: its sole frame in base coordinates, then world_T_base = world_T_sole,desired * (base_T_sole)^-1
-        const int t_now = kt.tick2[kt.phase];
-        const int side = ((t_now + kt.phase0[inst]) % (2 * kt.step_ticks)) / kt.step_ticks;     // 0: left is the stance foot
-        const int jf = md->frame_joint[side];
-        const double* T = S + OFF_TW + jf * 12;
-        double Rj[9], fR[9], fp[3], Ra[9], pa[3], d[3];
+        // anchor foot: world_T_base = world_T_sole,desired * (base_T_sole)^-1
+        const double* sd = S + OFF_SD + side * 12;       // desired pose of the anchor sole: p (3), R (9)
+        const double* Fs = S + OFF_FRB + side * 12;      // its frame in base coordinates: R (9), p (3)
+        double Rd[9], Rs[9], ps[3], d[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { Rj[k] = T[k]; fR[k] = md->frame_R[side][k]; }
+        for (int k = 0; k < 9; ++k) { Rd[k] = sd[3 + k]; Rs[k] = Fs[k]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) fp[k] = md->frame_p[side][k];
-        mat3_mul(Rj, fR, Ra);
-        mat3_vec(Rj, fp, d);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pa[k] = T[9 + k] + d[k];
-        const double* sd = state + inst * kStateLen + (side ? 36 : 24);      // desired pose of the anchor sole: p (3), R (9)
-        double Rd[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rd[k] = sd[3 + k];
-        // Rb = Rd Ra'
+        for (int k = 0; k < 3; ++k) ps[k] = Fs[9 + k];
+        // Rb = Rd Rs'
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) Rb[3 * r + c] = Rd[3 * r] * Ra[3 * c] + Rd[3 * r + 1] * Ra[3 * c + 1] + Rd[3 * r + 2] * Ra[3 * c + 2];
-        mat3_vec(Rb, pa, d);
+            for (int c = 0; c < 3; ++c) Rb[3 * r + c] = Rd[3 * r] * Rs[3 * c] + Rd[3 * r + 1] * Rs[3 * c + 1] + Rd[3 * r + 2] * Rs[3 * c + 2];
+        mat3_vec(Rb, ps, d);
 #pragma unroll
         for (int k = 0; k < 3; ++k) pb[k] = sd[k] - d[k];
-        // this lane's joint frame, now in world coordinates
-        double Rl[9], pl[3];
+    } else {
+        const double* b = S + OFF_SD;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rl[k] = Rw[k];
+        for (int k = 0; k < 3; ++k) pb[k] = b[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pl[k] = pw[k];
-        mat3_mul(Rb, Rl, Rw);
-        mat3_vec(Rb, pl, d);
+        for (int k = 0; k < 9; ++k) Rb[k] = b[3 + k];
+    }
+    // this lane's joint frame in world coordinates
+    double Rw[9], pw[3];
+    frame_mul(Rb, pb, Ra, pa, Rw, pw);
+    // attached frames, world
+    if (i < 3) {
+        double Rg[9], pg[3];
+        frame_mul(Rb, pb, Rf, pf, Rg, pg);
+        double* F = S + OFF_FR + i * 12;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pw[k] = pb[k] + d[k];
-        wcqp::wave_lds_fence();               // every lane has read the base-frame tree: it may be overwritten
-        if (is_joint) {
-            double* Tm = S + OFF_TW + j * 12;
+        for (int k = 0; k < 9; ++k) F[k] = Rg[k];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Tm[k] = Rw[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) Tm[9 + k] = pw[k];
-        }
-        wcqp::wave_lds_fence();
+        for (int k = 0; k < 3; ++k) F[9 + k] = pg[k];
     }
     // joint axis in world (a rotation about the axis leaves it unchanged: R_w * axis)
     double aw[3];
     mat3_vec(Rw, ax, aw);
-    // link first moments; the root link goes to slot 32 (lane 0)
+    WCQP_KSTAMP(4);
+    // link first moment {m c, m} of the own joint's link, and of the root link
+    double e4[4] = {0.0, 0.0, 0.0, 0.0};
     if (is_joint) {
-        double cl[3], cj[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) cj[k] = md->com[jc][k];
+        double cl[3];
         mat3_vec(Rw, cj, cl);
-        const double m = md->mass[jc];
-        double* e = S + OFF_MC + j * 4;
+        const double m = mj;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) e[k] = m * (pw[k] + cl[k]);
-        e[3] = m;
+        for (int k = 0; k < 3; ++k) e4[k] = m * (pw[k] + cl[k]);
+        e4[3] = m;
     }
-    if (i == 0) {
-        double rc[3], cr[3];
+    double root4[4];
+    {
+        double cr[3];
+        mat3_vec(Rb, rootc, cr);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rc[k] = md->root_com[k];
-        mat3_vec(Rb, rc, cr);
-        double* e = S + OFF_MC + 32 * 4;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) e[k] = md->root_mass * (pb[k] + cr[k]);
-        e[3] = md->root_mass;
+        for (int k = 0; k < 3; ++k) root4[k] = root_mass * (pb[k] + cr[k]);
+        root4[3] = root_mass;
     }
-    // attached frames (lanes 0..2)
-    if (i < 3) {
-        const int jf = md->frame_joint[i];
-        const double* T = S + OFF_TW + jf * 12;
-        // (T of the frame's joint is complete: all levels are done)
-        double Rj[9], fR[9], fp[3], Rf[9], d[3];
+    wcqp::wave_lds_fence();                   // TW is dead (anchor and attached frames have been read): PS / MC overlay it
+    // subtree first moment and mass of this lane's joint; total first moment and mass
+    double ms = 0.0, mcs[3] = {0.0, 0.0, 0.0}, tot[4];
+    if (shp.dfs_contig) {
+        // the subtree of joint j is the index range j .. sub_end[j]: differences of prefix sums over the lanes
+        double ps4[4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { Rj[k] = T[k]; fR[k] = md->frame_R[i][k]; }
+        for (int k = 0; k < 4; ++k) ps4[k] = half_scan(e4[k]);
+        double* P = S + OFF_PS + i * 4;
+        *reinterpret_cast<double2*>(P) = make_double2(ps4[0], ps4[1]);
+        *reinterpret_cast<double2*>(P + 2) = make_double2(ps4[2], ps4[3]);
+        wcqp::wave_lds_fence();
+        const double* Pe = S + OFF_PS + (6 + sub_end) * 4;
+        const double* Pb = S + OFF_PS + (i > 0 ? i - 1 : 0) * 4;
+        const double* Pt = S + OFF_PS + 31 * 4;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) fp[k] = md->frame_p[i][k];
-        mat3_mul(Rj, fR, Rf);
-        mat3_vec(Rj, fp, d);
-        double* F = S + OFF_FR + i * 12;
+        for (int k = 0; k < 4; ++k) tot[k] = Pt[k] + root4[k];
+        if (is_joint) {
+            mcs[0] = Pe[0] - Pb[0]; mcs[1] = Pe[1] - Pb[1]; mcs[2] = Pe[2] - Pb[2]; ms = Pe[3] - Pb[3];
+        }
+    } else {
+        if (is_joint) {
+            double* e = S + OFF_MC + j * 4;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) F[k] = Rf[k];
+            for (int k = 0; k < 4; ++k) e[k] = e4[k];
+        }
+        wcqp::wave_lds_fence();
 #pragma unroll
-        for (int k = 0; k < 3; ++k) F[9 + k] = T[9 + k] + d[k];
-    }
-    wcqp::wave_lds_fence();
-    // total first moment and mass: lanes 0..3 take one component each
-    if (i < 4) {
-        double acc = S[OFF_MC + 32 * 4 + i];
-        for (int k = 0; k < dof; ++k) acc += S[OFF_MC + k * 4 + i];
-        S[OFF_CT + i] = acc;
-    }
-    // subtree first moment and mass of this lane's joint
-    double ms = 0.0, mcs[3] = {0.0, 0.0, 0.0};
-    if (is_joint) {
-        unsigned dm = md->desc_mask[jc];
-        while (dm) {
-            const int k = __ffs(dm) - 1;
-            dm &= dm - 1;
+        for (int k = 0; k < 4; ++k) tot[k] = root4[k];
+        for (int k = 0; k < dof; ++k) {
             const double* e = S + OFF_MC + k * 4;
-            mcs[0] += e[0]; mcs[1] += e[1]; mcs[2] += e[2]; ms += e[3];
+            tot[0] += e[0]; tot[1] += e[1]; tot[2] += e[2]; tot[3] += e[3];
+        }
+        if (is_joint) {
+            unsigned dm = md->desc_mask[jc];
+            while (dm) {
+                const int k = __ffs(dm) - 1;
+                dm &= dm - 1;
+                const double* e = S + OFF_MC + k * 4;
+                mcs[0] += e[0]; mcs[1] += e[1]; mcs[2] += e[2]; ms += e[3];
+            }
         }
     }
-    wcqp::wave_lds_fence();
-    const double Mtot = S[OFF_CT + 3];
-    const double iM = 1.0 / Mtot;
+    const double iM = 1.0 / tot[3];
     double ctot[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) ctot[k] = S[OFF_CT + k] * iM;
+    for (int k = 0; k < 3; ++k) ctot[k] = tot[k] * iM;
 
+    WCQP_KSTAMP(5);
     // ---------------- Jacobian columns ---------------------------------------------------------
     if (live && i < 6 + dof) {
         const int ncol = 6 + dof;
@@ -276,7 +365,7 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, int batch,
                 const double d[3] = {F[9] - pb[0], F[10] - pb[1], F[11] - pb[2]};
                 cross3(e, d, lin);                           // column k of -S(p_f - p_b) = e_k x (p_f - p_b)
                 ang[0] = e[0]; ang[1] = e[1]; ang[2] = e[2];
-            } else if ((md->path_mask[f] >> j) & 1u) {
+            } else if ((on_path >> f) & 1u) {
                 const double d[3] = {F[9] - pw[0], F[10] - pw[1], F[11] - pw[2]};
                 cross3(aw, d, lin);
                 ang[0] = aw[0]; ang[1] = aw[1]; ang[2] = aw[2];
@@ -306,6 +395,7 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, int batch,
         for (int r = 0; r < 3; ++r) J[r * ncol + i] = lin[r];
     }
     // ---------------- actual poses into the IK state block ---------------------------------------
+    WCQP_KSTAMP(6);
     if (state && live) {
         double* s = state + inst * kStateLen;
         if (i < 12) {                                         // left / right foot: p (3), R (9)
@@ -367,12 +457,18 @@ int kin_enqueue_tick(wcqp_kin_t h, int batch, const wcqp_tick::KinTick& kt, cons
     if (!h || !h->d_model || batch < 1 || !state || !q || !J_left || !J_right || !J_neck || !J_com) return WCQP_E_INVALID;
     if (!kt.tick2 || !kt.phase0 || !kt.sel || !kt.sel_built || !kt.hull_A || !kt.hull_b || !kt.hull_nc || kt.step_ticks < 1) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((batch + 1) / 2);
-    hipLaunchKernelGGL(kin_jacobians_kernel<true>, dim3(grid), dim3(64), 0, stream, h->d_model, batch, nullptr, q,
+    hipLaunchKernelGGL(kin_jacobians_kernel<true>, dim3(grid), dim3(64), 0, stream, h->d_model,
+                       KinShape{h->hd.dof, h->hd.n_rounds, h->hd.dfs_contig}, batch, nullptr, q,
                        J_left, J_right, J_neck, J_com, state, kt);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }
 }  // namespace wcqp
+
+#ifdef WCQP_KIN_STAMPS
+static double* g_kin_dbg = nullptr;
+extern "C" void wcqp_kin_set_debug(void* p) { g_kin_dbg = static_cast<double*>(p); }
+#endif
 
 extern "C" {
 
@@ -385,13 +481,15 @@ int wcqp_kin_create(const wcqp_kin_params* params, wcqp_kin_t* out) {
     if (!h) return WCQP_E_NOMEM;
     h->p = *params;
     KinDev& d = h->hd;
-    d.dof = n; d.max_level = 0; d.root_mass = params->root_mass; d.total_mass = params->root_mass;
+    d.dof = n; d.root_mass = params->root_mass; d.total_mass = params->root_mass;
+    int level[kMaxDof], max_level = 0;
+    for (int r = 0; r < kMaxRounds; ++r) for (int j = 0; j < kMaxDof; ++j) d.up[r][j] = -1;
     for (int j = 0; j < n; ++j) {
         const int par = params->parent[j];
         if (par >= j || par < -1 || !(params->mass[j] >= 0.0)) { delete h; return WCQP_E_INVALID; }
-        d.parent[j] = par;
-        d.level[j] = par < 0 ? 1 : d.level[par] + 1;
-        if (d.level[j] > d.max_level) d.max_level = d.level[j];
+        d.up[0][j] = par;
+        level[j] = par < 0 ? 1 : level[par] + 1;
+        if (level[j] > max_level) max_level = level[j];
         std::memcpy(d.R0[j], params->R0[j], sizeof(d.R0[j]));
         std::memcpy(d.p0[j], params->p0[j], sizeof(d.p0[j]));
         double nrm = 0.0;
@@ -403,7 +501,21 @@ int wcqp_kin_create(const wcqp_kin_params* params, wcqp_kin_t* out) {
         d.desc_mask[j] = 1u << j;
     }
     if (!(d.total_mass > 0.0)) { delete h; return WCQP_E_INVALID; }
-    for (int j = n - 1; j >= 0; --j) if (d.parent[j] >= 0) d.desc_mask[d.parent[j]] |= d.desc_mask[j];
+    for (int j = n - 1; j >= 0; --j) if (d.up[0][j] >= 0) d.desc_mask[d.up[0][j]] |= d.desc_mask[j];
+    // pointer-jumping links: a joint at level L is complete after ceil(log2 L) rounds
+    d.n_rounds = 0;
+    while ((1 << d.n_rounds) < max_level) ++d.n_rounds;
+    for (int r = 0; r + 1 < kMaxRounds; ++r)
+        for (int j = 0; j < n; ++j) d.up[r + 1][j] = d.up[r][j] < 0 ? -1 : d.up[r][d.up[r][j]];
+    // are the subtrees index ranges (a depth-first numbering, as in the shipped joint lists)?
+    d.dfs_contig = 1;
+    for (int j = 0; j < n; ++j) {
+        const unsigned m = d.desc_mask[j] >> j;               // bit 0 = j itself
+        int len = 0;
+        while ((m >> len) & 1u) ++len;
+        if ((m >> len) != 0u) d.dfs_contig = 0;
+        d.sub_end[j] = j + len - 1;
+    }
     std::memcpy(d.root_com, params->root_com, sizeof(d.root_com));
     for (int f = 0; f < 3; ++f) {
         const int jf = params->frame_joint[f];
@@ -412,7 +524,7 @@ int wcqp_kin_create(const wcqp_kin_params* params, wcqp_kin_t* out) {
         std::memcpy(d.frame_R[f], params->frame_R[f], sizeof(d.frame_R[f]));
         std::memcpy(d.frame_p[f], params->frame_p[f], sizeof(d.frame_p[f]));
         unsigned m = 0;
-        for (int k = jf; k >= 0; k = d.parent[k]) m |= 1u << k;
+        for (int k = jf; k >= 0; k = d.up[0][k]) m |= 1u << k;
         d.path_mask[f] = m;
     }
     *out = h;
@@ -435,8 +547,13 @@ int wcqp_kin_jacobians_device(wcqp_kin_t h, int32_t batch, const double* base, c
     const int rc = ensure_device(h);
     if (rc != WCQP_OK) return rc;
     const unsigned grid = (unsigned)((batch + 1) / 2);
-    hipLaunchKernelGGL(kin_jacobians_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, h->d_model, batch, base, q,
-                       J_left, J_right, J_neck, J_com, state, wcqp_tick::KinTick{});
+    wcqp_tick::KinTick kt{};
+#ifdef WCQP_KIN_STAMPS
+    kt.hull_b = g_kin_dbg;
+#endif
+    hipLaunchKernelGGL(kin_jacobians_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, h->d_model,
+                       KinShape{h->hd.dof, h->hd.n_rounds, h->hd.dfs_contig}, batch, base, q,
+                       J_left, J_right, J_neck, J_com, state, kt);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }
