@@ -2,7 +2,7 @@
 set -o pipefail
 mkdir -p gpurun_out
 L=gpurun_out/kin2.log; : > $L
-for lib in "" kw3; do
+for lib in kp2 kp3; do
   [ -n "$lib" ] && export WCQP_LIB_PATH=$PWD/walking-controllers_amd/csrc/build/diag/libwcqp_$lib.so
   echo "== lib ${lib:-product}" >> $L
   timeout -k 10 300 python bench.py --workload kin --batch 65536 --steps 50 --warmup 5 >> $L 2>&1 || { tail -20 $L; exit 1; }

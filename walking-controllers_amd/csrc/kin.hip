@@ -107,7 +107,7 @@ struct KinShape { int dof, n_rounds, dfs_contig; };
 // memory), so every global load is issued at the top, in the order of use: q and the joint's constants, the
 // pointer-jumping links, the pose input (one element per lane, handed round through LDS), the link and frame constants.
 #ifndef WCQP_KIN_WAVES
-#define WCQP_KIN_WAVES 4                       // waves per SIMD the register budget is set for
+#define WCQP_KIN_WAVES 3                       // waves per SIMD the register budget is set for (4: the tick variant spills)
 #endif
 template <bool TICK>
 __global__ __launch_bounds__(64, WCQP_KIN_WAVES)
