@@ -141,13 +141,12 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     // ---------------- phase 0: loads ------------------------------------------------------------
     const int v0i = 6 + j, v1i = var1 ? 22 + j : 0;           // index into the per-variable constant tables
     const double sd0 = prm->sd[j], sd1 = prm->sd[col1], isd0 = prm->isd[j], isd1 = prm->isd[col1];
-    const bool osqp_form = prm->form == WCQP_IK_FORM_OSQP;
-    const double k_pos_foot = prm->k_pos_foot, k_att_foot = prm->k_att_foot, k_pos_com = prm->k_pos_com;
-    const double kap = prm->kappa * (-prm->k_neck);
     const double kq0 = prm->kq[v0i], kq1 = prm->kq[v1i], qreg0 = prm->qreg[v0i], qreg1 = prm->qreg[v1i];
-    const int fast_ok = prm->fast_ok;
     double a0[NROWS_IN], a1[NROWS_IN];     // columns of [J_left; J_right; J_com; J_neck]
     double q0, q1;
+    bool osqp_form;
+    double k_pos_foot, k_att_foot, k_pos_com, kap;
+    int fast_ok;
     // tick pipeline: this tick's DCM-MPC on the same 16 lanes (what mpc_condensed_kernel does as a launch of its
     // own elsewhere): window [t, t+N] of the instance's DCM trajectory, hull rows of the current contact pair,
     // x0 = measured DCM, u_prev = previous output.  Its result stays in registers for the glue below.
@@ -198,6 +197,12 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
         for (int r = 0; r < 3; ++r) { a0[15 + r] = jn[r * kNV + fc0]; a1[15 + r] = jn[r * kNV + fc1]; }
         __builtin_amdgcn_sched_barrier(0);
+        // the scalar settings are read only now: in front of the column loads their (cold) scalar-cache misses would sit in
+        // the same s_waitcnt as the Jacobian pointers and hold the 36 loads back
+        osqp_form = prm->form == WCQP_IK_FORM_OSQP;
+        k_pos_foot = prm->k_pos_foot; k_att_foot = prm->k_att_foot; k_pos_com = prm->k_pos_com;
+        kap = prm->kappa * (-prm->k_neck);
+        fast_ok = prm->fast_ok;
 #pragma unroll
         for (int m = 0; m < 5; ++m) st[m * 16 + j] = sreg[m];
         st[80 + j] = sreg[5];        // unconditional (slots 87..95 are spare): a predicated store makes hipcc sink the LOAD into the branch, behind the column loads
@@ -209,6 +214,15 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         }
     }
     wcqp::wave_lds_fence();
+#ifdef WCQP_IK4_EXIT_AFTER_LOADS
+    {   // diagnostic build: the launch up to the point where every input has landed
+        double acc = q0 + q1 + st[j];
+#pragma unroll
+        for (int r = 0; r < NROWS_IN; ++r) acc += a0[r] + a1[r];
+        if (live) dq_out[inst * kDof + j] = acc + sd0 + sd1 + isd0 + isd1 + kq0 + kq1 + qreg0 + qreg1 + (double)fast_ok + k_pos_foot + k_att_foot + k_pos_com + kap + (osqp_form ? 1.0 : 0.0);
+        return;
+    }
+#endif
 
     WCQP_STAMP(1);
     // ---------------- phase 1: task rhs b (lanes 0..14) and neck target e (lanes 13..15) ------------------
