@@ -12,6 +12,15 @@ instance cold-started.  Inputs are resident in HBM before the timed region start
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Consecutive steps are independent batches (cold start: nothing is carried from one step to the next), so up to
+batch 16384 - where a launch is one wave per SIMD that spends half its life waiting for its inputs - step i goes to
+pipeline i % 2, each pipeline with its own streams and output buffers, and the input loads of one batch run under the
+arithmetic of the previous one (`--pipelines 1` for strictly one batch at a time).  The timed steps are handed to the
+library in one host call (`wcqp_qp_enqueue_steps`: the same two launches per step, without an FFI round trip each).
+Timed region: barrier + torch.cuda.synchronize() -> K steps -> every stream's completion event (hipEventSynchronize),
+MAX over ranks; the device-wide synchronize follows the clock (`ms_per_step_incl_device_sync` keeps it inside: on this
+ROCm stack that call costs the host 55-75 us with the device already idle, a fifth of a 20-step region).
+
 Instances are independent, so ranks shard the batch with no data-path collective
 (`scaling: weak`, fixed per-GPU batch); `--exchange` adds the RCCL scatter of inputs from
 rank 0 and gather of solutions to every step and reports that rate too.
@@ -19,7 +28,8 @@ rank 0 and gather of solutions to every step and reports that r
 The JSON line carries
   roofline      HBM roofline of the dominant kernel (the IK kernel): algorithmic bytes per
                 launch (5240 B/IK-QP x batch) / its average launch duration,
-                measured with HIP events on the launch stream over the timed steps;
+                measured with HIP events on the launch stream in a pass of its own after the timed steps
+                (back-to-back launches of that kernel alone, cold and resident inputs);
   cpu_baseline  oracle/wc_oracle.c (OSQP-algorithm restatement for the MPC, dense dual
                 active set for the IK) timed on this box's host cores on a bounded sample.
 """
@@ -57,6 +67,10 @@ def main():
                     help="qp workload: 2 = the (independent) MPC and IK batches go to two HIP streams and may overlap; "
                          "0 = auto: 2 up to 32768 robots per GPU (+18 %% at 4096, +18 %% at 8192, +9 %% at 16384, +2 %% at 32768: the MPC "
                          "kernel fits beside the IK kernel), 1 above (at 65536 the overlap slows the IK kernel more than it saves)")
+    ap.add_argument("--pipelines", type=int, default=0,
+                    help="qp workload: consecutive steps are independent batches (cold start, nothing carried over), so step i goes to "
+                         "pipeline i %% P, each with its own streams and output buffers, and the load phase of one batch overlaps the "
+                         "arithmetic of the previous one; 0 = 2 for batches up to 16384 (one wave per SIMD per launch), else 1")
     ap.add_argument("--horizon", type=int, default=50, help="qp workload: MPC horizon N (BASELINE: 50; the shipped controllerHorizon 2 s is N = 200: auxiliary line)")
     ap.add_argument("--input-sets", type=int, default=0, help="qp workload: distinct input sets visited round-robin (0 = enough for > 320 MB, at least 2)")
     ap.add_argument("--ik-jac", choices=["mixed", "auto", "general"], default="mixed",
@@ -118,15 +132,16 @@ def main():
     set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
     K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
-    u0 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
-    mstat = torch.zeros(B, dtype=torch.int32, device=dev)
-    mact = torch.zeros(B, dtype=torch.int32, device=dev)
-    mmar = torch.zeros(B, dtype=torch.float64, device=dev)
-    dq = torch.zeros(B, 23, dtype=torch.float64, device=dev)
-    istat = torch.zeros(B, dtype=torch.int32, device=dev)
-    ilo = torch.zeros(B, dtype=torch.int32, device=dev)
-    iup = torch.zeros(B, dtype=torch.int32, device=dev)
-    iit = torch.zeros(B, dtype=torch.int32, device=dev)
+    P = args.pipelines if args.pipelines > 0 else (2 if (B <= 16384 and not (args.exchange and world > 1)) else 1)
+
+    def outputs():
+        return dict(u0=torch.zeros(B, 2, dtype=torch.float64, device=dev), mstat=torch.zeros(B, dtype=torch.int32, device=dev),
+                    mact=torch.zeros(B, dtype=torch.int32, device=dev), mmar=torch.zeros(B, dtype=torch.float64, device=dev),
+                    dq=torch.zeros(B, 23, dtype=torch.float64, device=dev), istat=torch.zeros(B, dtype=torch.int32, device=dev),
+                    ilo=torch.zeros(B, dtype=torch.int32, device=dev), iup=torch.zeros(B, dtype=torch.int32, device=dev),
+                    iit=torch.zeros(B, dtype=torch.int32, device=dev))
+    outs = [outputs() for _ in range(P)]
+    u0, dq = outs[0]["u0"], outs[0]["dq"]
 
     mpc = wca.MpcSolver(horizon=NH)
     ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
@@ -138,17 +153,33 @@ def main():
     two_streams = n_streams == 2
     stream_mpc = torch.cuda.Stream(dev) if two_streams else stream
     sp_mpc = stream_mpc.cuda_stream
+    # pipeline 0 = (stream, stream_mpc); further pipelines get streams of their own
+    pipes = [(stream, stream_mpc)] + [(torch.cuda.Stream(dev), torch.cuda.Stream(dev) if two_streams else None) for _ in range(P - 1)]
+    pipes = [(a, b if b is not None else a) for a, b in pipes]
+    all_streams = []
+    for pr in pipes:
+        for x in pr:
+            if not any(x is y for y in all_streams):
+                all_streams.append(x)
+    if not any(stream is y for y in all_streams):
+        all_streams.append(stream)
     N1 = mb["ref"].shape[1]
 
-    def launch_mpc(d, on=None):
-        mpc.solve_device(B, d["x0"].data_ptr(), d["ref"].data_ptr(), N1, d["u_prev"].data_ptr(),
-                         d["hull_A"].data_ptr(), d["hull_b"].data_ptr(), d["hull_nc"].data_ptr(),
-                         u0.data_ptr(), mstat.data_ptr(), mact.data_ptr(), mmar.data_ptr(), sp_mpc if on is None else on)
+    # raw device addresses, looked up once: a step is two kernels of 5 and 15 us, and a dozen Tensor.data_ptr() calls per
+    # launch cost the host about as much as the launch itself
+    for d in sets:
+        d["_mpc"] = tuple(d[k].data_ptr() for k in ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc"))
+        d["_ik"] = tuple(d[k].data_ptr() for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state"))
+    optr = [{k: v.data_ptr() for k, v in o.items()} for o in outs]
+    sptr = [(a.cuda_stream, b.cuda_stream) for a, b in pipes]
 
-    def launch_ik(d, solver=None):
-        (solver or ik).solve_device(B, d["J_left"].data_ptr(), d["J_right"].data_ptr(), d["J_neck"].data_ptr(),
-                                    d["J_com"].data_ptr(), d["q"].data_ptr(), d["state"].data_ptr(),
-                                    dq.data_ptr(), istat.data_ptr(), ilo.data_ptr(), iup.data_ptr(), 0, iit.data_ptr(), sp)
+    def launch_mpc(d, on=None, k=0):
+        o, m = optr[k], d["_mpc"]
+        mpc.solve_device(B, m[0], m[1], N1, m[2], m[3], m[4], m[5], o["u0"], o["mstat"], o["mact"], o["mmar"], sptr[k][1] if on is None else on)
+
+    def launch_ik(d, solver=None, k=0):
+        o, m = optr[k], d["_ik"]
+        (solver or ik).solve_device(B, m[0], m[1], m[2], m[3], m[4], m[5], o["dq"], o["istat"], o["ilo"], o["iup"], 0, o["iit"], sptr[k][0])
 
     # optional RCCL exchange (rank 0 owns the whole batch)
     exch = None
@@ -179,26 +210,37 @@ def main():
         if exch:
             exch[0]()
             stream_mpc.wait_stream(stream)          # the MPC stream starts behind the scatter ...
-        launch_mpc(d)
-        launch_ik(d)
+        launch_mpc(d, k=i % P)
+        launch_ik(d, k=i % P)
         if exch:
             stream.wait_stream(stream_mpc)          # ... and the gather behind both solves: the two batches still overlap
             exch[1]()
 
     def barrier():
-        # an event per stream, polled: hipDeviceSynchronize alone wakes up ~50 us late, which a 20-step timed region of
-        # 0.35 ms would carry as a 15 % error; the synchronize that follows returns at once
-        evs = [torch.cuda.Event() for _ in range(2)]
-        evs[0].record(stream); evs[1].record(stream_mpc)
-        while not (evs[0].query() and evs[1].query()):
+        """Every stream the steps use has finished (an event at its tail, polled, then hipEventSynchronize'd), all ranks
+        have, and the device is idle.  Returns the host time at which this rank's work was COMPLETE - the end of a timed
+        region - and the time after the device-wide synchronize that follows: on this ROCm stack the first
+        hipDeviceSynchronize after a burst of launches costs the host 55-75 us with the device already idle
+        (tools/sync_cost.py; it is 4 us on a quiet process), which is 20 % of a 20-step region and no part of the steps."""
+        evs = [torch.cuda.Event() for _ in all_streams]
+        for e, st_ in zip(evs, all_streams):
+            e.record(st_)
+        while not all(e.query() for e in evs):      # polled: a blocking wait wakes up ~50 us late
             pass
+        for e in evs:
+            e.synchronize()
+        t_done = time.perf_counter()
         torch.cuda.synchronize(dev)
+        t_sync = time.perf_counter()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        return t_done, t_sync
 
     # the inputs and the zero-filled outputs were enqueued on the default stream: the MPC stream starts behind them
-    stream_mpc.wait_stream(stream)
+    for st_ in all_streams:
+        if st_ is not stream:
+            st_.wait_stream(stream)
     # set-up, not warm-up: every input set is read once, so that none of them is touched for the first time (page-table
     # walks of a fresh allocation) inside a short timed region; the W warm-up steps follow
     if not exch:
@@ -208,20 +250,43 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    # the argument records of the timed steps (set-up): step i = the MPC and the IK call of step(i), handed to the
+    # library in ONE host call (wcqp_qp_enqueue_steps) - through ctypes a launch costs the host ~4.4 us, two kernels of 5
+    # and 15 us per step leave the card waiting for the host otherwise
+    recs = None
+    if not exch:
+        recs = (wca.capi.QpStep * args.steps)()
+        for n in range(args.steps):
+            i = args.warmup + n
+            d, k = sets[i % K], i % P
+            o, m, q_ = optr[k], d["_mpc"], d["_ik"]
+            r = recs[n]
+            r.x0, r.ref, r.ref_len, r.u_prev, r.hull_A, r.hull_b, r.hull_nc = m[0], m[1], N1, m[2], m[3], m[4], m[5]
+            r.u0, r.mpc_status, r.mpc_active, r.mpc_margin, r.mpc_stream = o["u0"], o["mstat"], o["mact"], o["mmar"], sptr[k][1] or None
+            r.J_left, r.J_right, r.J_neck, r.J_com, r.q, r.state = q_
+            r.dq, r.ik_status, r.active_lower, r.active_upper, r.foot_err, r.iters = o["dq"], o["istat"], o["ilo"], o["iup"], None, o["iit"]
+            r.ik_stream = sptr[k][0] or None
     # ---- the timed region: K steps, nothing but the launches (no events, no host reads) ----------------------------
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if recs is not None:
+        wca.capi.qp_enqueue_steps(mpc, ik, B, recs)
+    else:
+        for i in range(args.steps):
+            step(args.warmup + i)
+    t_enq = time.perf_counter() - t0
+    t_done, t_sync = barrier()
+    elapsed = t_done - t0
+    elapsed_sync = max_over_ranks(dist, torch, dev, t_sync - t0)
     elapsed = max_over_ranks(dist, torch, dev, elapsed)
-    stream.wait_stream(stream_mpc)
+    for st_ in all_streams:
+        if st_ is not stream:
+            stream.wait_stream(st_)
 
-    # sanity: the timed work really solved the problems
-    n_ok_ik = int((istat == 0).sum().item())
-    n_ok_mpc = int((mstat == 0).sum().item())
-    ik_iters = float(iit.double().mean().item())
-    frac_active = float(((ilo | iup) != 0).double().mean().item())
+    # sanity: the timed work really solved the problems (every pipeline's last batch)
+    n_ok_ik = min(int((o["istat"] == 0).sum().item()) for o in outs)
+    n_ok_mpc = min(int((o["mstat"] == 0).sum().item()) for o in outs)
+    ik_iters = float(outs[0]["iit"].double().mean().item())
+    frac_active = float(((outs[0]["ilo"] | outs[0]["iup"]) != 0).double().mean().item())
 
     # ---- kernel durations, measured AFTER the timed region in short passes of their own: HIP events on the launch
     # stream around n back-to-back launches of one kernel (a pair of event records costs about as much as a launch, so
@@ -241,12 +306,12 @@ def main():
     # the IK kernel alone: a MIXED-structure handle launches exactly the one kernel (AUTO adds the nearly empty
     # fall-back launch behind it, timed separately below)
     ik_one = ik if args.ik_jac != "auto" else wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=wca.IK_JAC_MIXED)
-    ik_ms = kernel_ms(lambda d: launch_ik(d, ik_one), stream, True)
-    ik_ms_res = kernel_ms(lambda d: launch_ik(d, ik_one), stream, False)
+    ik_ms = kernel_ms(lambda d: launch_ik(d, ik_one), pipes[0][0], True)
+    ik_ms_res = kernel_ms(lambda d: launch_ik(d, ik_one), pipes[0][0], False)
     mpc_ms = kernel_ms(lambda d: launch_mpc(d, sp), stream, True)
     mpc_ms_res = kernel_ms(lambda d: launch_mpc(d, sp), stream, False)
     ik_auto = wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=wca.IK_JAC_AUTO)
-    ik_auto_ms = kernel_ms(lambda d: launch_ik(d, ik_auto), stream, True)
+    ik_auto_ms = kernel_ms(lambda d: launch_ik(d, ik_auto), pipes[0][0], True)
 
     total_qp = 2 * B * world * args.steps
     value = total_qp / elapsed
@@ -261,8 +326,13 @@ def main():
                          "(iCub 23 DoF, 15 eq rows, %s form, v_max=%.2f rad/s) B=%d; 2 QP solves per robot-tick"
                          % (NH, 4 * NH + 2, B, args.ik_form, args.ik_vmax, B)),
             "batch_per_gpu": B, "global_batch": B * world, "horizon": NH, "dof": 23,
-            "input_sets": K, "input_bytes_per_set": set_bytes, "ik_jacobian_structure": args.ik_jac,
-            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ""),
+            "input_sets": K, "input_bytes_per_set": set_bytes, "ik_jacobian_structure": args.ik_jac, "pipelines": P,
+            "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
+            "timed_region": "barrier + torch.cuda.synchronize() -> K steps -> completion events of every stream used (hipEventSynchronize), "
+                            "MAX over ranks; the device-wide synchronize that follows adds %.0f us of host time with the device idle "
+                            "(ms_per_step_incl_device_sync)" % (1e6 * (elapsed_sync - elapsed)),
+            "ms_per_step_incl_device_sync": 1e3 * elapsed_sync / args.steps,
+            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else "") + ("; %d independent batches in flight (step i -> pipeline i %% %d)" % (P, P) if P > 1 else ""),
         },
         "roofline": {
             "bound": "hbm", "kernel": ik_kernel,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WCQP_VERSION 200
+#define WCQP_VERSION 201
 
 /* return codes */
 #define WCQP_OK              0
@@ -246,6 +246,31 @@ int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
                        double* dq, int32_t* status,
                        uint32_t* active_lower, uint32_t* active_upper,
                        double* foot_err, int32_t* iters);
+
+/* =====================================================================================
+ * Several solve calls in one host call.  A robot-tick batch at the BASELINE size is two kernels of
+ * about 5 and 15 us, which is what their two launches cost a host that reaches this library through
+ * an FFI (ctypes, cgo, JNI): wcqp_qp_enqueue_steps takes an array of argument records and makes, for
+ * each record in order, exactly the calls
+ *     wcqp_mpc_solve_device(mpc, batch, <the record's MPC arguments>, mpc_stream)
+ *     wcqp_ik_solve_device (ik,  batch, <the record's IK arguments>,  ik_stream)
+ * (a record whose x0 is NULL skips the MPC call, one whose J_left is NULL the IK call).  Nothing
+ * else changes: same kernels, same streams, same results; the first failing call's code is returned
+ * and *n_done (may be NULL) says how many records were enqueued completely.
+ */
+typedef struct wcqp_qp_step {
+    /* wcqp_mpc_solve_device */
+    const double* x0; const double* ref; int32_t ref_len; const double* u_prev;
+    const double* hull_A; const double* hull_b; const int32_t* hull_nc;
+    double* u0; int32_t* mpc_status; uint32_t* mpc_active; double* mpc_margin; void* mpc_stream;
+    /* wcqp_ik_solve_device */
+    const double* J_left; const double* J_right; const double* J_neck; const double* J_com;
+    const double* q; const double* state;
+    double* dq; int32_t* ik_status; uint32_t* active_lower; uint32_t* active_upper;
+    double* foot_err; int32_t* iters; void* ik_stream;
+} wcqp_qp_step;
+int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch,
+                          int32_t n_steps, const wcqp_qp_step* steps, int32_t* n_done);
 
 /* =====================================================================================
  * Batched kinematics: forward kinematics of a kinematic tree and the free-floating

@@ -448,3 +448,13 @@ def test_ik_posture_update_reaches_the_solve(wca, qs):
     for i in range(0, B, 5):
         r = qs.ik_exact(p, qs.ik_inputs_from_batch(b, i), "qpoases")
         assert after["status"][i] == 0 and np.abs(after["dq"][i] - r["dq"]).max() <= SOL_TOL
+
+
+def test_qp_enqueue_steps_equals_the_single_calls():
+    """wcqp_qp_enqueue_steps makes the same calls as wcqp_mpc_solve_device + wcqp_ik_solve_device per record
+    (tests/helpers/enqueue_steps_check.py: three records, two streams, one record without an MPC part, bit for bit).
+    In a process of its own: torch brings its own HIP runtime and has to initialise before libwcqp's does."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "enqueue_steps_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "enqueue_steps ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "wcqp_hull_from_feet_device", "wcqp_hull_from_feet_host",
     "wcqp_kin_create", "wcqp_kin_destroy", "wcqp_kin_jacobians_device", "wcqp_kin_jacobians_host",
     "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download",
+    "wcqp_qp_enqueue_steps",
 )
 
 
@@ -59,6 +60,27 @@ class IkParams(C.Structure):
                 ("k_att_foot", C.c_double), ("k_neck", C.c_double),
                 ("rho", C.c_double), ("tol", C.c_double), ("algorithm", C.c_int32),
                 ("jacobian_structure", C.c_int32)]
+
+
+class QpStep(C.Structure):
+    """wcqp_qp_step: the arguments of one wcqp_mpc_solve_device + one wcqp_ik_solve_device call (raw device addresses)."""
+    _fields_ = [("x0", C.c_void_p), ("ref", C.c_void_p), ("ref_len", C.c_int32), ("u_prev", C.c_void_p),
+                ("hull_A", C.c_void_p), ("hull_b", C.c_void_p), ("hull_nc", C.c_void_p),
+                ("u0", C.c_void_p), ("mpc_status", C.c_void_p), ("mpc_active", C.c_void_p), ("mpc_margin", C.c_void_p),
+                ("mpc_stream", C.c_void_p),
+                ("J_left", C.c_void_p), ("J_right", C.c_void_p), ("J_neck", C.c_void_p), ("J_com", C.c_void_p),
+                ("q", C.c_void_p), ("state", C.c_void_p),
+                ("dq", C.c_void_p), ("ik_status", C.c_void_p), ("active_lower", C.c_void_p), ("active_upper", C.c_void_p),
+                ("foot_err", C.c_void_p), ("iters", C.c_void_p), ("ik_stream", C.c_void_p)]
+
+
+def qp_enqueue_steps(mpc, ik, batch, steps):
+    """wcqp_qp_enqueue_steps: `steps` is a ctypes array of QpStep (build it once, replay it often); mpc / ik are the
+    MpcSolver / IkSolver handles (either may be None when no record uses it)."""
+    done = C.c_int32(0)
+    check(lib().wcqp_qp_enqueue_steps(mpc._h if mpc is not None else None, ik._h if ik is not None else None, int(batch),
+                                      len(steps), steps, C.byref(done)), "wcqp_qp_enqueue_steps")
+    return done.value
 
 
 class KinParams(C.Structure):
@@ -124,6 +146,7 @@ def lib() -> C.CDLL:
         L.wcqp_tick_upload.argtypes = [C.c_void_p, C.POINTER(TickInputs)]
         L.wcqp_tick_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.wcqp_tick_download.argtypes = [C.c_void_p, C.POINTER(TickOutputs)]
+        L.wcqp_qp_enqueue_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 

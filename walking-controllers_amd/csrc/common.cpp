@@ -78,6 +78,26 @@ const char* wcqp_strerror(int code) {
 
 int wcqp_version(void) { return WCQP_VERSION; }
 
+int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_steps, const wcqp_qp_step* steps, int32_t* n_done) {
+    if (n_done) *n_done = 0;
+    if (n_steps < 0 || (n_steps > 0 && !steps)) return WCQP_E_INVALID;
+    for (int32_t k = 0; k < n_steps; ++k) {
+        const wcqp_qp_step& s = steps[k];
+        if (s.x0) {
+            const int rc = wcqp_mpc_solve_device(mpc, batch, s.x0, s.ref, s.ref_len, s.u_prev, s.hull_A, s.hull_b, s.hull_nc,
+                                                 s.u0, s.mpc_status, s.mpc_active, s.mpc_margin, s.mpc_stream);
+            if (rc != WCQP_OK) return rc;
+        }
+        if (s.J_left) {
+            const int rc = wcqp_ik_solve_device(ik, batch, s.J_left, s.J_right, s.J_neck, s.J_com, s.q, s.state,
+                                                s.dq, s.ik_status, s.active_lower, s.active_upper, s.foot_err, s.iters, s.ik_stream);
+            if (rc != WCQP_OK) return rc;
+        }
+        if (n_done) *n_done = k + 1;
+    }
+    return WCQP_OK;
+}
+
 int wcqp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
