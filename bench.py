@@ -14,7 +14,7 @@ instance cold-started.  Inputs are resident in HBM before the timed region start
 
 Consecutive steps are independent batches (cold start: nothing is carried from one step to the next), so up to
 batch 16384 - where a launch is one wave per SIMD that spends half its life waiting for its inputs - step i goes to
-pipeline i % 2, each pipeline with its own streams and output buffers, and the input loads of one batch run under the
+pipeline i % 3, each pipeline with its own streams and output buffers, and the input loads of one batch run under the
 arithmetic of the previous one (`--pipelines 1` for strictly one batch at a time).  The timed steps are handed to the
 library in one host call (`wcqp_qp_enqueue_steps`: the same two launches per step, without an FFI round trip each).
 Timed region: barrier + torch.cuda.synchronize() -> K steps -> every stream's completion event (hipEventSynchronize),
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--pipelines", type=int, default=0,
                     help="qp workload: consecutive steps are independent batches (cold start, nothing carried over), so step i goes to "
                          "pipeline i %% P, each with its own streams and output buffers, and the load phase of one batch overlaps the "
-                         "arithmetic of the previous one; 0 = 2 for batches up to 16384 (one wave per SIMD per launch), else 1")
+                         "arithmetic of the previous one; 0 = 3 for batches up to 16384 (one wave per SIMD per launch), else 1")
     ap.add_argument("--horizon", type=int, default=50, help="qp workload: MPC horizon N (BASELINE: 50; the shipped controllerHorizon 2 s is N = 200: auxiliary line)")
     ap.add_argument("--input-sets", type=int, default=0, help="qp workload: distinct input sets visited round-robin (0 = enough for > 320 MB, at least 2)")
     ap.add_argument("--ik-jac", choices=["mixed", "auto", "general"], default="mixed",
@@ -132,7 +132,7 @@ def main():
     set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
     K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
-    P = args.pipelines if args.pipelines > 0 else (2 if (B <= 16384 and not (args.exchange and world > 1)) else 1)
+    P = args.pipelines if args.pipelines > 0 else (3 if (B <= 16384 and not (args.exchange and world > 1)) else 1)
 
     def outputs():
         return dict(u0=torch.zeros(B, 2, dtype=torch.float64, device=dev), mstat=torch.zeros(B, dtype=torch.int32, device=dev),
@@ -149,7 +149,9 @@ def main():
     ik = wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=jac)
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
-    n_streams = args.streams if args.streams else (2 if B <= 32768 else 1)
+    # one stream per pipeline: wcqp_qp_enqueue_steps then makes the two calls of a step as ONE launch (IK and MPC workgroups
+    # side by side); --streams 2 keeps them as two launches on two streams (the exchange path always does)
+    n_streams = args.streams if args.streams else (2 if (args.exchange and world > 1 and B <= 32768) else 1)
     two_streams = n_streams == 2
     stream_mpc = torch.cuda.Stream(dev) if two_streams else stream
     sp_mpc = stream_mpc.cuda_stream
@@ -225,8 +227,9 @@ def main():
         evs = [torch.cuda.Event() for _ in all_streams]
         for e, st_ in zip(evs, all_streams):
             e.record(st_)
-        while not all(e.query() for e in evs):      # polled: a blocking wait wakes up ~50 us late
-            pass
+        if not os.environ.get("WCQP_BENCH_NOPOLL"):
+            while not all(e.query() for e in evs):      # polled: a blocking wait wakes up ~50 us late
+                pass
         for e in evs:
             e.synchronize()
         t_done = time.perf_counter()
@@ -313,6 +316,23 @@ def main():
     ik_auto = wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=wca.IK_JAC_AUTO)
     ik_auto_ms = kernel_ms(lambda d: launch_ik(d, ik_auto), pipes[0][0], True)
 
+    # the launch the timed region is made of when a step's two calls share a stream: IK and MPC workgroups in one grid
+    pair_mode = recs is not None and not two_streams and args.ik_jac != "general"
+    pair_ms = pair_ms_res = None
+    if pair_mode:
+        one = {}
+        for d in sets:
+            r1 = (wca.capi.QpStep * 1)()
+            r, o, m, q_ = r1[0], optr[0], d["_mpc"], d["_ik"]
+            r.x0, r.ref, r.ref_len, r.u_prev, r.hull_A, r.hull_b, r.hull_nc = m[0], m[1], N1, m[2], m[3], m[4], m[5]
+            r.u0, r.mpc_status, r.mpc_active, r.mpc_margin, r.mpc_stream = o["u0"], o["mstat"], o["mact"], o["mmar"], sptr[0][0] or None
+            r.J_left, r.J_right, r.J_neck, r.J_com, r.q, r.state = q_
+            r.dq, r.ik_status, r.active_lower, r.active_upper, r.foot_err, r.iters = o["dq"], o["istat"], o["ilo"], o["iup"], None, o["iit"]
+            r.ik_stream = sptr[0][0] or None
+            one[id(d)] = r1
+        pair_ms = kernel_ms(lambda d: wca.capi.qp_enqueue_steps(mpc, ik_one, B, one[id(d)]), pipes[0][0], True)
+        pair_ms_res = kernel_ms(lambda d: wca.capi.qp_enqueue_steps(mpc, ik_one, B, one[id(d)]), pipes[0][0], False)
+
     total_qp = 2 * B * world * args.steps
     value = total_qp / elapsed
     ik_kernel = {"mixed": "ik4_kernel", "auto": "ik4_kernel", "general": "ik3_kernel"}[args.ik_jac]
@@ -332,17 +352,27 @@ def main():
                             "MAX over ranks; the device-wide synchronize that follows adds %.0f us of host time with the device idle "
                             "(ms_per_step_incl_device_sync)" % (1e6 * (elapsed_sync - elapsed)),
             "ms_per_step_incl_device_sync": 1e3 * elapsed_sync / args.steps,
-            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else "") + ("; %d independent batches in flight (step i -> pipeline i %% %d)" % (P, P) if P > 1 else ""),
+            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ("; MPC and IK of a step in one launch" if not exch else "")) + ("; %d independent batches in flight (step i -> pipeline i %% %d)" % (P, P) if P > 1 else ""),
         },
-        "roofline": {
+        # the dominant kernel of the timed region: the one-launch step (IK + MPC workgroups; algorithmic bytes = both QPs'
+        # per robot-tick) - or the IK kernel where the two calls are separate launches
+        "roofline": ({
+            "bound": "hbm", "kernel": "qp_pair_kernel",
+            "achieved": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "avg_launch_ms": pair_ms, "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B,
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (> the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6),
+            "frac_resident_inputs": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": pair_ms_res,
+        } if pair_mode else {
             "bound": "hbm", "kernel": ik_kernel,
             "achieved": ik_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ik_gbs / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": ik_ms, "algorithmic_bytes_per_launch": IK_BYTES_PER_QP * B,
             "inputs": "cold: %d input sets of %.1f MB visited round-robin (> the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6),
             "frac_resident_inputs": IK_BYTES_PER_QP * B / (ik_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": ik_ms_res,
-        },
+        }),
         "kernels": {
-            "ik_ms": ik_ms, "ik_qps_per_gpu": B / (ik_ms * 1e-3),
+            "ik_kernel": ik_kernel, "ik_ms": ik_ms, "ik_ms_resident_inputs": ik_ms_res, "ik_qps_per_gpu": B / (ik_ms * 1e-3),
+            "ik_hbm_frac": ik_gbs / HBM_PEAK_GBS, "ik_hbm_frac_resident_inputs": IK_BYTES_PER_QP * B / (ik_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # secondary bounds.  fp64 vector: ~8.5 kflop per IK-QP with the base-eliminated kernel (row
             # operations 1.6 k, sweep 2.5 k, x / bounds ~1.4 k, rhs / rot errors ~0.5 k + the Gram tile below) against
             # 78.6 TFLOP/s; fp64 MFMA: 6 v_mfma_f64_16x16x4 per IK-QP = 12.3 kflop issued (the Gram product C C', 24 x 13 x 13
@@ -362,7 +392,7 @@ def main():
         try:
             tr = json.load(open(traffic_file)).get("per_batch", {}).get(str(B))
             if tr:
-                out["roofline"]["traffic"] = tr.get("ik_hbm_bytes_per_launch")
+                out["roofline"]["traffic"] = tr.get("pair_hbm_bytes_per_launch" if pair_mode else "ik_hbm_bytes_per_launch")
         except Exception:
             pass
 

@@ -254,9 +254,12 @@ int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
  * each record in order, exactly the calls
  *     wcqp_mpc_solve_device(mpc, batch, <the record's MPC arguments>, mpc_stream)
  *     wcqp_ik_solve_device (ik,  batch, <the record's IK arguments>,  ik_stream)
- * (a record whose x0 is NULL skips the MPC call, one whose J_left is NULL the IK call).  Nothing
- * else changes: same kernels, same streams, same results; the first failing call's code is returned
- * and *n_done (may be NULL) says how many records were enqueued completely.
+ * (a record whose x0 is NULL skips the MPC call, one whose J_left is NULL the IK call).  Same
+ * streams, same results; a record whose two calls name the SAME stream is enqueued as one launch
+ * whose workgroups split between the two problems (the IK handle's default kernel permitting) - the
+ * MPC waves then run in the slots the IK waves leave idle while they wait for their inputs.  The
+ * first failing call's code is returned and *n_done (may be NULL) says how many records were
+ * enqueued completely.
  */
 typedef struct wcqp_qp_step {
     /* wcqp_mpc_solve_device */

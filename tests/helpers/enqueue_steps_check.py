@@ -1,4 +1,6 @@
-"""Run by tests/test_gpu_parity.py::test_qp_enqueue_steps_equals_the_single_calls in a process of its own."""
+"""Run by tests/test_gpu_parity.py::test_qp_enqueue_steps_equals_the_single_calls in a process of its own: three records
+against the single calls, bit for bit - record 0 on two streams (two launches), record 1 without an MPC part, record 2 with
+both calls on one stream (the one-launch form: IK and MPC workgroups in one grid)."""
 import os, sys
 import numpy as np
 import torch
@@ -42,7 +44,7 @@ def main():
             r.x0, r.ref, r.ref_len, r.u_prev = m["x0"].data_ptr(), m["ref"].data_ptr(), N1, m["u_prev"].data_ptr()
             r.hull_A, r.hull_b, r.hull_nc = m["hull_A"].data_ptr(), m["hull_b"].data_ptr(), m["hull_nc"].data_ptr()
             r.u0, r.mpc_status, r.mpc_active, r.mpc_margin = o["u0"].data_ptr(), o["ms"].data_ptr(), o["ma"].data_ptr(), o["mm"].data_ptr()
-            r.mpc_stream = streams[1].cuda_stream
+            r.mpc_stream = streams[1].cuda_stream if n == 0 else streams[0].cuda_stream     # record 2: both calls on one stream = ONE launch
         r.J_left, r.J_right, r.J_neck, r.J_com = (i[k].data_ptr() for k in ("J_left", "J_right", "J_neck", "J_com"))
         r.q, r.state = i["q"].data_ptr(), i["state"].data_ptr()
         r.dq, r.ik_status, r.active_lower, r.active_upper = o["dq"].data_ptr(), o["st"].data_ptr(), o["lo"].data_ptr(), o["up"].data_ptr()

@@ -13,6 +13,7 @@ prof() { # name, bench args...
 }
 prof bench_b4096 --steps 200 --warmup 20
 prof bench_b4096_driver --steps 20 --warmup 5
+prof bench_b4096_two_launches --steps 200 --warmup 20 --streams 2 --pipelines 1
 prof bench_b65536 --steps 50 --warmup 10 --batch 65536
 prof bench_b4096_osqp --steps 200 --warmup 20 --ik-form osqp
 prof bench_b4096_n200 --steps 200 --warmup 20 --horizon 200
@@ -37,11 +38,14 @@ for P in "$P1" "$P2" "$P3"; do
 done
 cd $R
 python3 tools/pmc/summarize.py $O/pmc > $O/pmc_summary.json 2>&1
+python3 tools/pmc/make_traffic.py $O/pmc_summary.json > $O/traffic.json 2>&1
 python3 tools/pmc/summarize_ik.py $O/pmc_ik > $O/pmc_ik4_detail.json 2>&1
 # bench lines (no profiler attached)
 timeout -k 10 400 python3 bench.py --steps 200 --warmup 20 > $O/bench_b4096.json 2> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_b4096_driver.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --ik-jac auto > $O/bench_b4096_driver_auto.json 2>> $O/bench.err
+timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --pipelines 1 > $O/bench_b4096_one_batch_at_a_time.json 2>> $O/bench.err
+timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --pipelines 1 --streams 2 > $O/bench_b4096_two_launches.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 --batch 65536 --no-cpu-baseline > $O/bench_b65536.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --ik-form osqp --no-cpu-baseline > $O/bench_b4096_osqp.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --horizon 200 --no-cpu-baseline > $O/bench_b4096_n200.json 2>> $O/bench.err

@@ -83,6 +83,11 @@ int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n
     if (n_steps < 0 || (n_steps > 0 && !steps)) return WCQP_E_INVALID;
     for (int32_t k = 0; k < n_steps; ++k) {
         const wcqp_qp_step& s = steps[k];
+        {
+            const int rc = wcqp::qp_pair_enqueue(mpc, ik, batch, s);      // one launch for both calls when they share a stream
+            if (rc == WCQP_OK) { if (n_done) *n_done = k + 1; continue; }
+            if (rc != WCQP_E_UNSUPPORTED) return rc;
+        }
         if (s.x0) {
             const int rc = wcqp_mpc_solve_device(mpc, batch, s.x0, s.ref, s.ref_len, s.u_prev, s.hull_A, s.hull_b, s.hull_nc,
                                                  s.u0, s.mpc_status, s.mpc_active, s.mpc_margin, s.mpc_stream);

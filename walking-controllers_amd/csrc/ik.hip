@@ -576,6 +576,35 @@ int wcqp_ik_solve_device(wcqp_ik_t h, int32_t batch,
 #endif
 }
 
+}  // extern "C"
+
+namespace wcqp {
+// wcqp_qp_enqueue_steps: both calls of a record as one launch when they go to the same stream and the IK handle runs the
+// base-eliminated kernel; WCQP_E_UNSUPPORTED = "make the two calls" (not an error)
+int qp_pair_enqueue(wcqp_mpc_t mpc, wcqp_ik_t h, int batch, const wcqp_qp_step& s) {
+    if (!mpc || !h || batch < 1 || !s.x0 || !s.J_left || s.mpc_stream != s.ik_stream) return WCQP_E_UNSUPPORTED;
+    const bool want4 = h->p.algorithm == WCQP_IK_ALG_BASE_ELIM || h->p.algorithm == WCQP_IK_ALG_DEFAULT;
+    if (!(want4 && h->hp.fast_ok && h->p.jacobian_structure != WCQP_IK_JAC_GENERAL)) return WCQP_E_UNSUPPORTED;
+    if (s.ref_len < 1 || !s.ref || !s.u_prev || !s.hull_A || !s.hull_b || !s.hull_nc || !s.u0 || !s.mpc_status) return WCQP_E_INVALID;
+    if (!s.J_right || !s.J_neck || !s.J_com || !s.q || !s.state || !s.dq || !s.ik_status) return WCQP_E_INVALID;
+    int rc = ensure_device(h);
+    if (rc != WCQP_OK) return rc;
+    rc = mpc_prepare(mpc);
+    if (rc != WCQP_OK) return rc;
+    wcqp_mpc::MpcDeviceConsts c;
+    mpc_device_consts(mpc, &c);
+    rc = wcqp_ik::ik4_launch_pair(h->d_prm, batch, s.J_left, s.J_right, s.J_neck, s.J_com, s.q, s.state, s.dq, s.ik_status,
+                                  s.active_lower, s.active_upper, s.foot_err, s.iters,
+                                  c, s.x0, s.ref, s.ref_len, s.u_prev, s.hull_A, s.hull_b, s.hull_nc, s.u0, s.mpc_status, s.mpc_active, s.mpc_margin,
+                                  (hipStream_t)s.ik_stream);
+    if (rc != WCQP_OK || h->p.jacobian_structure == WCQP_IK_JAC_MIXED) return rc;
+    return wcqp_ik::ik3_launch_list(h->d_prm, batch, s.J_left, s.J_right, s.J_neck, s.J_com, s.q, s.state, s.dq, s.ik_status,
+                                    s.active_lower, s.active_upper, s.foot_err, s.iters, (hipStream_t)s.ik_stream);
+}
+}  // namespace wcqp
+
+extern "C" {
+
 int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,
                        const double* J_left, const double* J_right, const double* J_neck, const double* J_com,
                        const double* q, const double* state,

@@ -105,8 +105,8 @@ __device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpre
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 
 template <bool TICK>
-__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
-void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
+__device__ __forceinline__
+void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
                 const double* __restrict__ JN, const double* __restrict__ JC,
                 const double* qpos, const double* __restrict__ state,
@@ -1014,9 +1014,80 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     }
 }
 
+template <bool TICK>
+__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
+void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
+                const double* __restrict__ JL, const double* __restrict__ JR,
+                const double* __restrict__ JN, const double* __restrict__ JC,
+                const double* qpos, const double* __restrict__ state,
+                double* __restrict__ dq_out, int* __restrict__ status_out,
+                unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
+                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
+{
+    ik4_body<TICK>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td);
+}
+
+// Both QPs of a batch of robot-ticks in ONE launch (wcqp_qp_enqueue_steps, a record whose two calls go to the same
+// stream): workgroups 0 .. ik_blocks-1 are the IK kernel above, the rest the DCM-MPC kernel of mpc.hip (same device
+// functions, same results).  At the BASELINE batch each is one wave per SIMD, so the MPC waves run in the slots the IK
+// waves leave idle while their inputs are on the way, and the host pays one launch per step instead of two.
+struct MpcPairArgs {
+    wcqp_mpc::MpcDeviceConsts c;
+    const double* x0; const double* ref; int ref_len; const double* u_prev;
+    const double* hull_A; const double* hull_b; const int* hull_nc;
+    double* u0; int* status; unsigned* active; double* margin;
+};
+__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
+void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
+                    const double* __restrict__ JL, const double* __restrict__ JR,
+                    const double* __restrict__ JN, const double* __restrict__ JC,
+                    const double* qpos, const double* __restrict__ state,
+                    double* __restrict__ dq_out, int* __restrict__ status_out,
+                    unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
+                    double* __restrict__ ferr_out, int* __restrict__ iters_out, int ik_blocks, MpcPairArgs m)
+{
+    if ((int)blockIdx.x >= ik_blocks) {
+        __shared__ __attribute__((aligned(16))) double s_hull[wcqp_mpc::kInstPerWave][WCQP_HULL_ROWS][4];
+        const int lane = threadIdx.x;
+        const int sub = lane / wcqp_mpc::kLanesPerInstance, t = lane % wcqp_mpc::kLanesPerInstance;
+        const long inst_raw = (long)((int)blockIdx.x - ik_blocks) * wcqp_mpc::kInstPerWave + sub;
+        const bool live = inst_raw < batch;
+        const long inst = live ? inst_raw : (long)batch - 1;
+        const double2* rp = reinterpret_cast<const double2*>(m.ref) + inst * m.ref_len;
+        double ux, uy, margin;
+        int st;
+        unsigned mask;
+        wcqp_mpc::mpc_row_solve(m.c, t, inst, m.x0, rp, m.ref_len, m.u_prev, m.hull_A, m.hull_b, m.hull_nc, inst, s_hull[sub], ux, uy, st, mask, margin);
+        if (t == 0 && live) {
+            reinterpret_cast<double2*>(m.u0)[inst] = make_double2(ux, uy);
+            m.status[inst] = st;
+            if (m.active) m.active[inst] = mask;
+            if (m.margin) m.margin[inst] = margin;
+        }
+        return;
+    }
+    ik4_body<false>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{});
+}
+
 }  // namespace
 
 namespace wcqp_ik {
+
+int ik4_launch_pair(const IkDeviceParams* d_prm, int batch,
+                    const double* JL, const double* JR, const double* JN, const double* JC,
+                    const double* q, const double* state, double* dq, int* status,
+                    unsigned* alo, unsigned* aup, double* ferr, int* iters,
+                    const wcqp_mpc::MpcDeviceConsts& c, const double* x0, const double* ref, int ref_len, const double* u_prev,
+                    const double* hull_A, const double* hull_b, const int* hull_nc,
+                    double* u0, int* mstatus, unsigned* mactive, double* mmargin, hipStream_t stream) {
+    const int ik_blocks = (batch + 3) / 4;
+    const int mpc_blocks = (batch + wcqp_mpc::kInstPerWave - 1) / wcqp_mpc::kInstPerWave;
+    MpcPairArgs m{c, x0, ref, ref_len, u_prev, hull_A, hull_b, hull_nc, u0, mstatus, mactive, mmargin};
+    hipLaunchKernelGGL(qp_pair_kernel, dim3((unsigned)(ik_blocks + mpc_blocks)), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+                       dq, status, alo, aup, ferr, iters, ik_blocks, m);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
 
 int ik4_launch(const IkDeviceParams* d_prm, int batch,
                const double* JL, const double* JR, const double* JN, const double* JC,

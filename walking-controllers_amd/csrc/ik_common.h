@@ -2,6 +2,7 @@
 // ik2.hip: null-space formulation).  Internal, not part of the ABI.
 #pragma once
 #include "wcqp_internal.h"
+#include "mpc_device.h"
 
 namespace wcqp_ik {
 
@@ -381,6 +382,13 @@ namespace wcqp_ik {
 int ik3_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
                     const double* JL, const double* JR, const double* JN, const double* JC,
                     unsigned* alo, unsigned* aup, hipStream_t stream);
+int ik4_launch_pair(const IkDeviceParams* d_prm, int batch,
+                    const double* JL, const double* JR, const double* JN, const double* JC,
+                    const double* q, const double* state, double* dq, int* status,
+                    unsigned* alo, unsigned* aup, double* ferr, int* iters,
+                    const wcqp_mpc::MpcDeviceConsts& c, const double* x0, const double* ref, int ref_len, const double* u_prev,
+                    const double* hull_A, const double* hull_b, const int* hull_nc,
+                    double* u0, int* mstatus, unsigned* mactive, double* mmargin, hipStream_t stream);
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
                     const double* JL, const double* JR, const double* JN, const double* JC,
                     unsigned* alo, unsigned* aup, hipStream_t stream);

@@ -41,6 +41,7 @@ int mpc_horizon(wcqp_mpc_t h);
 int mpc_prepare(wcqp_mpc_t h);     // uploads the handle's device constants now (graph capture forbids it later)
 int ik_prepare(wcqp_ik_t h);
 const void* ik_device_params(wcqp_ik_t h);     // IkDeviceParams* in HBM (after ik_prepare)
+int qp_pair_enqueue(wcqp_mpc_t mpc, wcqp_ik_t ik, int batch, const wcqp_qp_step& s);   // WCQP_E_UNSUPPORTED: make the two calls instead
 bool ik_fast_ok(wcqp_ik_t h);                  // the handle qualifies for the base-eliminated kernel (ik4.hip)
 void mpc_dynamics(wcqp_mpc_t h, double* a, double* b);
 int kin_prepare(wcqp_kin_t h);
