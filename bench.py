@@ -363,6 +363,11 @@ def main():
             "traffic": None, "avg_launch_ms": pair_ms, "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B,
             "inputs": "cold: %d input sets of %.1f MB visited round-robin (> the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6),
             "frac_resident_inputs": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": pair_ms_res,
+            # `frac` prices ONE launch running alone (back-to-back launches of the kernel on one stream: what `rocprofv3 --stats`
+            # reports for a --pipelines 1 run); with P batches in flight the launches overlap, each takes longer, and the
+            # card as a whole moves this many algorithmic bytes per second through the timed region:
+            "timed_region": {"batches_in_flight": P, "achieved": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9,
+                             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
         } if pair_mode else {
             "bound": "hbm", "kernel": ik_kernel,
             "achieved": ik_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ik_gbs / HBM_PEAK_GBS,

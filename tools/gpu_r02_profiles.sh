@@ -14,6 +14,7 @@ prof() { # name, bench args...
 prof bench_b4096 --steps 200 --warmup 20
 prof bench_b4096_driver --steps 20 --warmup 5
 prof bench_b4096_two_launches --steps 200 --warmup 20 --streams 2 --pipelines 1
+prof bench_b4096_one_batch_at_a_time --steps 200 --warmup 20 --pipelines 1
 prof bench_b65536 --steps 50 --warmup 10 --batch 65536
 prof bench_b4096_osqp --steps 200 --warmup 20 --ik-form osqp
 prof bench_b4096_n200 --steps 200 --warmup 20 --horizon 200
