@@ -1,0 +1,12 @@
+/* Prints the layout of the by-value structs of include/wcqp.h that foreign-function bindings mirror field by field
+   (tests/test_abi_host.py compares it with walking-controllers_amd/capi.py). */
+#include <stddef.h>
+#include <stdio.h>
+#include "wcqp.h"
+int main(void) {
+    printf("wcqp_qp_step %zu", sizeof(wcqp_qp_step));
+    printf(" %zu %zu %zu %zu %zu %zu %zu", offsetof(wcqp_qp_step, x0), offsetof(wcqp_qp_step, ref_len), offsetof(wcqp_qp_step, u_prev),
+           offsetof(wcqp_qp_step, hull_nc), offsetof(wcqp_qp_step, mpc_stream), offsetof(wcqp_qp_step, J_left), offsetof(wcqp_qp_step, ik_stream));
+    printf("\n");
+    return 0;
+}

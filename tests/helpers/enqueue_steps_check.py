@@ -9,10 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import walking_controllers_amd as wca
 
 
-def main():
+def main(B, jac):
     dev = torch.device("cuda", 0)
-    B = 777
-    mpc, ik = wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4)
+    mpc, ik = wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, jacobian_structure=jac)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     sets = []
     for seed in (5, 6, 7):
@@ -54,7 +53,7 @@ def main():
     for a, b in zip(ref_o, got_o):
         for k in a:
             assert torch.equal(a[k], b[k]), k
-    assert (got_o[1]["ms"] == -1).all() and (got_o[0]["ms"] == 0).all() and (got_o[2]["st"] == 0).sum() > 0.99 * B
+    assert (got_o[1]["ms"] == -1).all() and (got_o[0]["ms"] == 0).all() and (got_o[2]["st"] == 0).sum() >= 0.99 * B - 1
     # a bad record stops the walk and reports how far it got
     recs[1].dq = None
     try:
@@ -62,9 +61,11 @@ def main():
         raise AssertionError("a record without dq must be refused")
     except wca.WcqpError:
         pass
-    print("enqueue_steps ok")
 
 
 if __name__ == "__main__":
-    main()
+    for B in (1, 5, 777):                      # ragged: not a multiple of the 4 robots per wave
+        for jac in (wca.IK_JAC_MIXED, wca.IK_JAC_AUTO):
+            main(B, jac)
+    print("enqueue_steps ok")
 

@@ -102,3 +102,16 @@ def test_hull_rows_convention(wca):
     two = np.vstack([pts, wca.synth.foot_corners(np.array([0.05, -0.16]), 0.2)])
     A2, b2, nc2 = wca.synth.hull_rows(two)
     assert 5 <= nc2 <= 8 and ((A2[:nc2] @ two.T) <= b2[:nc2, None] + 1e-12).all()
+
+
+def test_qp_step_record_layout_matches_the_header(tmp_path):
+    """The ctypes mirror of wcqp_qp_step (an array of these crosses the FFI) has the header's size and field offsets."""
+    import subprocess
+    import walking_controllers_amd as wca
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "abi_layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "abi_layout.c"), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    S = wca.capi.QpStep
+    mine = [C.sizeof(S)] + [getattr(S, f).offset for f in ("x0", "ref_len", "u_prev", "hull_nc", "mpc_stream", "J_left", "ik_stream")]
+    assert out[0] == "wcqp_qp_step" and [int(x) for x in out[1:]] == mine

@@ -21,9 +21,16 @@ __device__ __forceinline__ double2 ldg2u(const double* p) {
     return make_double2(v.x, v.y);
 }
 
-template <int PAT>
-__global__ __launch_bounds__(64) void load_kernel(Set s, int batch, double* out) {
+// RES: 0 = a small kernel; 1 = + 13.6 KB of LDS per workgroup (ik4's); 2 = + a 200-VGPR footprint as well (ik4's 214)
+template <int PAT, int RES = 0>
+__global__ __launch_bounds__(64, 2) void load_kernel(Set s, int batch, double* out) {
+    __shared__ double lds[RES >= 1 ? 1700 : 1];
     const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15;
+    double pad[RES >= 2 ? 80 : 1];
+    if (RES >= 2) {
+#pragma unroll
+        for (int k = 0; k < 80; ++k) { pad[k] = (double)(lane + k); asm volatile("" : "+v"(pad[k])); }
+    }
     long inst = (long)blockIdx.x * 4 + grp;
     if (inst >= batch) inst = batch - 1;
     double acc = 0.0;
@@ -74,6 +81,11 @@ __global__ __launch_bounds__(64) void load_kernel(Set s, int batch, double* out)
 #pragma unroll
         for (int k = 0; k < 3; ++k) { const int e = j + 16 * k; const double2 v = ldg2u(s.JC + inst * 87 + 2 * (e < 43 ? e : 0)); acc += v.x + v.y; }
     }
+    if (RES >= 1) { lds[lane] = acc; __builtin_amdgcn_s_waitcnt(0); acc = lds[63 - lane]; }
+    if (RES >= 2) {
+#pragma unroll
+        for (int k = 0; k < 80; ++k) { asm volatile("" : "+v"(pad[k])); acc += pad[k]; }
+    }
     out[(long)blockIdx.x * 64 + lane] = acc;
 }
 
@@ -100,16 +112,19 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(reinterpret_cast<void**>(&out), (size_t)grid * 64 * sizeof(double)));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const char* names[3] = {"A: 8 B per lane, columns j / 16+j (ik4)", "B: 16 B per lane, columns 2j / 2j+1", "C: linear 16 B pieces"};
+    const char* names[5] = {"A: 8 B per lane, columns j / 16+j (ik4)", "B: 16 B per lane, columns 2j / 2j+1", "C: linear 16 B pieces",
+                            "A + 13.6 KB LDS per workgroup", "A + 13.6 KB LDS + 200 VGPRs"};
     for (int rep = 0; rep < 2; ++rep)
-    for (int pat = 0; pat < 3; ++pat) {
+    for (int pat = 0; pat < 5; ++pat) {
         for (int w = 0; w < 2; ++w) {
             if (w == 1) CHECK(hipEventRecord(e0, 0));
             for (int it = 0; it < launches; ++it) {
                 const Set& s = sets[it % K];
                 if (pat == 0) hipLaunchKernelGGL(load_kernel<0>, dim3(grid), dim3(64), 0, 0, s, batch, out);
                 else if (pat == 1) hipLaunchKernelGGL(load_kernel<1>, dim3(grid), dim3(64), 0, 0, s, batch, out);
-                else hipLaunchKernelGGL(load_kernel<2>, dim3(grid), dim3(64), 0, 0, s, batch, out);
+                else if (pat == 2) hipLaunchKernelGGL(load_kernel<2>, dim3(grid), dim3(64), 0, 0, s, batch, out);
+                else if (pat == 3) hipLaunchKernelGGL((load_kernel<0, 1>), dim3(grid), dim3(64), 0, 0, s, batch, out);
+                else hipLaunchKernelGGL((load_kernel<0, 2>), dim3(grid), dim3(64), 0, 0, s, batch, out);
             }
             if (w == 1) CHECK(hipEventRecord(e1, 0));
             CHECK(hipDeviceSynchronize());

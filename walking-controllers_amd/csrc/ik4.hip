@@ -578,6 +578,9 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const unsigned pm = prev_lo | prev_up;
             const int k0 = __popc(pm);
             if (k0 >= 1 && k0 <= KS) {
+                // slots at and above the largest previous set among the instances of the wave that try are skipped with
+                // wave-uniform branches (they would carry identity rows and zero columns): most robots come with 1-2 bounds
+                const int Kh = __ballot(k0 >= 4) != 0ull ? 4 : __ballot(k0 >= 3) != 0ull ? 3 : __ballot(k0 >= 2) != 0ull ? 2 : 1;
                 double* yp4 = S + OFF_YPV;                     // [KS][16]: YPV, RV, CV, ROWB are free until the general loop
                 unsigned m = pm;
                 double sgW[KS];
@@ -591,11 +594,13 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 wcqp::wave_lds_fence();
 #pragma unroll
                 for (int a = 0; a < KS; ++a) {
-                    const double* colp = S + OFF_CT + wS[a] * LDC;
-                    double t = 0.0;
+                    if (a < Kh) {
+                        const double* colp = S + OFF_CT + wS[a] * LDC;
+                        double t = 0.0;
 #pragma unroll
-                    for (int r = 0; r < NR; r += 2) { const double2 c2 = ld2(colp + r); t = fma(Hr[r], c2.x, t); t = fma(Hr[r + 1], c2.y, t); }
-                    yp4[a * 16 + j] = j < NR ? t : 0.0;
+                        for (int r = 0; r < NR; r += 2) { const double2 c2 = ld2(colp + r); t = fma(Hr[r], c2.x, t); t = fma(Hr[r + 1], c2.y, t); }
+                        yp4[a * 16 + j] = j < NR ? t : 0.0;
+                    }
                 }
                 wcqp::wave_lds_fence();
                 double ua0[KS], ua1[KS];
@@ -606,9 +611,11 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                     const double2 a2 = ld2(ct0 + r), b2 = ld2(ct1 + r);
 #pragma unroll
                     for (int a = 0; a < KS; ++a) {
-                        const double2 y2 = ld2(yp4 + a * 16 + r);
-                        ua0[a] = fma(a2.x, y2.x, ua0[a]); ua0[a] = fma(a2.y, y2.y, ua0[a]);
-                        ua1[a] = fma(b2.x, y2.x, ua1[a]); ua1[a] = fma(b2.y, y2.y, ua1[a]);
+                        if (a < Kh) {
+                            const double2 y2 = ld2(yp4 + a * 16 + r);
+                            ua0[a] = fma(a2.x, y2.x, ua0[a]); ua0[a] = fma(a2.y, y2.y, ua0[a]);
+                            ua1[a] = fma(b2.x, y2.x, ua1[a]); ua1[a] = fma(b2.y, y2.y, ua1[a]);
+                        }
                     }
                 }
                 double Rm[KS][KS], Ri[KS][KS], sv[KS];
@@ -621,18 +628,25 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 for (int a = 0; a < KS; ++a) {
                     const bool used = sgW[a] != 0.0;
 #pragma unroll
-                    for (int b = 0; b < KS; ++b) {
-                        const double g = at_var(tc0[b], tc1[b], wS[a]);               // sigma_b P[p_a][p_b]
-                        Rm[a][b] = (used && sgW[b] != 0.0) ? sgW[a] * g : (a == b ? 1.0 : 0.0);
-                        Ri[a][b] = a == b ? 1.0 : 0.0;
+                    for (int b = 0; b < KS; ++b) { Rm[a][b] = a == b ? 1.0 : 0.0; Ri[a][b] = a == b ? 1.0 : 0.0; }
+                    sv[a] = 0.0;
+                    if (a < Kh) {
+#pragma unroll
+                        for (int b = 0; b < KS; ++b) {
+                            if (b < Kh) {
+                                const double g = at_var(tc0[b], tc1[b], wS[a]);           // sigma_b P[p_a][p_b]
+                                Rm[a][b] = (used && sgW[b] != 0.0) ? sgW[a] * g : (a == b ? 1.0 : 0.0);
+                            }
+                        }
+                        const double xa = at_var(nu0, nu1, wS[a]);
+                        const double ba = sgW[a] > 0.0 ? at_var(hi0, hi1, wS[a]) : at_var(lo0, lo1, wS[a]);
+                        sv[a] = used ? sgW[a] * (xa - ba) : 0.0;
                     }
-                    const double xa = at_var(nu0, nu1, wS[a]);
-                    const double ba = sgW[a] > 0.0 ? at_var(hi0, hi1, wS[a]) : at_var(lo0, lo1, wS[a]);
-                    sv[a] = used ? sgW[a] * (xa - ba) : 0.0;
                 }
                 bool okw = true;
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {                 // Gauss-Jordan, no pivoting: R is SPD when the set is independent
+                    if (k >= Kh) continue;                     // identity rows above the slots in use
                     const double piv = Rm[k][k];
                     okw = okw && piv > 1e-12;
                     const double ip = wcqp::fast_rcp(piv);
