@@ -13,7 +13,7 @@ instance cold-started.  Inputs are resident in HBM before the timed region start
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Consecutive steps are independent batches (cold start: nothing is carried from one step to the next), so up to
-batch 16384 - where a launch is one wave per SIMD that spends half its life waiting for its inputs - step i goes to
+batch 32768 - at the BASELINE batch a launch is one wave per SIMD that spends half its life waiting for its inputs - step i goes to
 pipeline i % 3, each pipeline with its own streams and output buffers, and the input loads of one batch run under the
 arithmetic of the previous one (`--pipelines 1` for strictly one batch at a time).  The timed steps are handed to the
 library in one host call (`wcqp_qp_enqueue_steps`: the same two launches per step, without an FFI round trip each).
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--pipelines", type=int, default=0,
                     help="qp workload: consecutive steps are independent batches (cold start, nothing carried over), so step i goes to "
                          "pipeline i %% P, each with its own streams and output buffers, and the load phase of one batch overlaps the "
-                         "arithmetic of the previous one; 0 = 3 for batches up to 16384 (one wave per SIMD per launch), else 1")
+                         "arithmetic of the previous one; 0 = 3 for batches up to 32768 (one wave per SIMD per launch), else 1")
     ap.add_argument("--horizon", type=int, default=50, help="qp workload: MPC horizon N (BASELINE: 50; the shipped controllerHorizon 2 s is N = 200: auxiliary line)")
     ap.add_argument("--input-sets", type=int, default=0, help="qp workload: distinct input sets visited round-robin (0 = enough for > 320 MB, at least 2)")
     ap.add_argument("--ik-jac", choices=["mixed", "auto", "general"], default="mixed",
@@ -132,7 +132,7 @@ def main():
     set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
     K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
-    P = args.pipelines if args.pipelines > 0 else (3 if (B <= 16384 and not (args.exchange and world > 1)) else 1)
+    P = args.pipelines if args.pipelines > 0 else (3 if (B <= 32768 and not (args.exchange and world > 1)) else 1)
 
     def outputs():
         return dict(u0=torch.zeros(B, 2, dtype=torch.float64, device=dev), mstat=torch.zeros(B, dtype=torch.int32, device=dev),

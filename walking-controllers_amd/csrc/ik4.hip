@@ -70,14 +70,19 @@ constexpr int OFF_YPV = A_SIZE;       // [16] M^-1 C v
 constexpr int OFF_RV = A_SIZE + 16;   // [16] dual step per slot      (working sets of more than KS bounds)
 constexpr int OFF_CV = A_SIZE + 32;   // [16]
 constexpr int OFF_ROWB = A_SIZE + 48; // [16] row of the leaving slot
-constexpr int OFF_WI = A_SIZE + 64;   // [16] ints: variable of slot a
-constexpr int PER_INST = 424;         // = 8 mod 32: the four instances of a wave sit 16 banks apart
+//   variable of slot a (working sets of more than KS bounds): an int in entry 13 of row a of C^T (the zero row of the Gram
+//   tile, dead once the MFMAs have read it)
+constexpr int PER_INST = 408;         // = 24 mod 32: the four instances of a wave sit 16 banks apart; 13056 B per workgroup
 static_assert(OFF_CT + 24 * LDC + 2 <= A_SIZE && OFF_DB + 18 <= A_SIZE && OFF_PB + 12 * 18 <= A_SIZE, "LDS overlays");
-static_assert(OFF_WI + 8 <= PER_INST && OFF_DV + 16 <= PER_INST && (PER_INST % 32 == 24 || PER_INST % 32 == 8), "instances 16 banks apart");
+static_assert(OFF_ROWB + 16 <= PER_INST && OFF_DV + 16 <= PER_INST && (PER_INST % 32 == 24 || PER_INST % 32 == 8), "instances 16 banks apart");
+static_assert(KMAX <= 24, "one slot index per C^T row");
 static_assert(PER_INST * 8 * 4 * 12 <= 160 * 1024, "12 blocks per CU");
 
 #ifndef WCQP_IK4_WAVES
 #define WCQP_IK4_WAVES 2
+#endif
+#ifndef WCQP_IK4_KS
+#define WCQP_IK4_KS 4                 // bounds kept replicated in registers (more: the slot-per-lane loop)
 #endif
 
 #ifdef WCQP_IK_STAMPS
@@ -112,10 +117,8 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* qpos, const double* __restrict__ state,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
-                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
+                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td, double (*smem)[PER_INST])
 {
-    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
-
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int j = lane & 15;
@@ -477,14 +480,14 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         double* rvec = S + OFF_RV;
         double* cvec = S + OFF_CV;
         double* rowb = S + OFF_ROWB;
-        int* Wi = reinterpret_cast<int*>(S + OFF_WI);
+        auto Wi = [&](int a) -> int& { return *reinterpret_cast<int*>(S + OFF_CT + a * LDC + 13); };
         const int rowbase = lane & 48;
         bool pending = false;
         int p = 0;
         double sig = 0.0, s = 0.0, tp0 = 0.0, tp1 = 0.0, ppp = 1.0, mu_p = 0.0;
         bool done = false;
         int nW = 0;
-        constexpr int KS = 4;
+        constexpr int KS = WCQP_IK4_KS;
         double Rs[KS][KS], sgS[KS], muS[KS], tvS[KS], tc0[KS], tc1[KS];
         int wS[KS];
 #pragma unroll
@@ -580,7 +583,9 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             if (k0 >= 1 && k0 <= KS) {
                 // slots at and above the largest previous set among the instances of the wave that try are skipped with
                 // wave-uniform branches (they would carry identity rows and zero columns): most robots come with 1-2 bounds
-                const int Kh = __ballot(k0 >= 4) != 0ull ? 4 : __ballot(k0 >= 3) != 0ull ? 3 : __ballot(k0 >= 2) != 0ull ? 2 : 1;
+                int Kh = 1;
+#pragma unroll
+                for (int a = 2; a <= KS; ++a) Kh = __ballot(k0 >= a) != 0ull ? a : Kh;
                 double* yp4 = S + OFF_YPV;                     // [KS][16]: YPV, RV, CV, ROWB are free until the general loop
                 unsigned m = pm;
                 double sgW[KS];
@@ -723,7 +728,9 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         // slot Kw).  Skipped slots would have contributed exact zeros: results do not depend on Kw.
 #pragma unroll 1
         for (int pass = 0; pass < 1024 && small; ++pass) {
-            const int Kw = __ballot(sgS[3] != 0.0) != 0ull ? 4 : __ballot(sgS[2] != 0.0) != 0ull ? 3 : __ballot(sgS[1] != 0.0) != 0ull ? 2 : 1;
+            int Kw = 1;
+#pragma unroll
+            for (int a = 1; a < KS; ++a) Kw = __ballot(sgS[a] != 0.0) != 0ull ? a + 1 : Kw;
             if (!pending) {
                 if (nW >= KS) { small = false; break; }                      // a fifth bound: general loop
                 if (it >= max_iter) { st_code = WCQP_STATUS_MAX_ITER; done = true; small = false; break; }
@@ -829,7 +836,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
             for (int a = 0; a < KS; ++a) {
                 if (a == j) {
-                    s_live = sgS[a] != 0.0; s_var = wS[a]; s_sg = sgS[a]; s_mu = muS[a]; Wi[a] = wS[a];
+                    s_live = sgS[a] != 0.0; s_var = wS[a]; s_sg = sgS[a]; s_mu = muS[a]; Wi(a) = wS[a];
 #pragma unroll
                     for (int b = 0; b < KS; ++b) myR[b] = b >= a ? Rs[a][b] : Rs[b][a];
                 }
@@ -897,7 +904,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                                 myR[b] = (b == n) ? (me ? inz : -ra_inz) : u0;
                                 myR[b + 1] = (b + 1 == n) ? (me ? inz : -ra_inz) : u1;
                             }
-                            if (me) { s_live = true; s_var = p; s_sg = sig; s_mu = mu_p; Wi[n] = p; }
+                            if (me) { s_live = true; s_var = p; s_sg = sig; s_mu = mu_p; Wi(n) = p; }
                             if (p == j) { in_w0 = true; sig0 = sig; slot0 = n; }
                             if (p == col1) { in_w1 = true; sig1 = sig; slot1 = n; }
                             ++nW;
@@ -912,7 +919,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                                 for (int b = 0; b < KMAX; b += 2) st2(rowb + b, myR[b], myR[b + 1]);
                             }
                             wcqp::wave_lds_fence();
-                            const int wdrop = Wi[jd];
+                            const int wdrop = Wi(jd);
                             double myjd = 0.0;                        // Rinv[j][jd] (Rinv is symmetric: = row jd, entry j)
                             const double djj = rowb[jd];
                             myjd = rowb[j < KMAX ? j : 0];
@@ -1038,7 +1045,8 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
 {
-    ik4_body<TICK>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td);
+    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
+    ik4_body<TICK>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem);
 }
 
 // Both QPs of a batch of robot-ticks in ONE launch (wcqp_qp_enqueue_steps, a record whose two calls go to the same
@@ -1060,8 +1068,10 @@ void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                     unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                     double* __restrict__ ferr_out, int* __restrict__ iters_out, int ik_blocks, MpcPairArgs m)
 {
+    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
     if ((int)blockIdx.x >= ik_blocks) {
-        __shared__ __attribute__((aligned(16))) double s_hull[wcqp_mpc::kInstPerWave][WCQP_HULL_ROWS][4];
+        static_assert(wcqp_mpc::kInstPerWave * WCQP_HULL_ROWS * 4 <= 4 * PER_INST, "the hull rows fit the IK's LDS");
+        double (*s_hull)[WCQP_HULL_ROWS][4] = reinterpret_cast<double (*)[WCQP_HULL_ROWS][4]>(&smem[0][0]);
         const int lane = threadIdx.x;
         const int sub = lane / wcqp_mpc::kLanesPerInstance, t = lane % wcqp_mpc::kLanesPerInstance;
         const long inst_raw = (long)((int)blockIdx.x - ik_blocks) * wcqp_mpc::kInstPerWave + sub;
@@ -1080,7 +1090,7 @@ void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         }
         return;
     }
-    ik4_body<false>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{});
+    ik4_body<false>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem);
 }
 
 }  // namespace
