@@ -63,10 +63,10 @@ def main():
                     help="qp: configs[1]+[2] cold-start batches (default); tick: the device-resident receding-horizon "
                          "MPC->glue->IK tick of configs[3]/[4], one hipGraph replay per step")
     ap.add_argument("--no-graph", action="store_true", help="tick workload: plain launches instead of hipGraph replay")
-    ap.add_argument("--streams", type=int, choices=[0, 1, 2], default=0,
-                    help="qp workload: 2 = the (independent) MPC and IK batches go to two HIP streams and may overlap; "
-                         "0 = auto: 2 up to 32768 robots per GPU (+18 %% at 4096, +18 %% at 8192, +9 %% at 16384, +2 %% at 32768: the MPC "
-                         "kernel fits beside the IK kernel), 1 above (at 65536 the overlap slows the IK kernel more than it saves)")
+    ap.add_argument("--streams", type=int, choices=[0, 1, 2, 3, 4], default=0,
+                    help="qp workload: 0/1 = the MPC and the IK of a step are ONE launch (wcqp_qp_enqueue_steps, both on one stream: "
+                         "default); 2 = two launches on two streams.  tick workload: robot groups, each with a pipeline and a stream of its own "
+                         "(0 = 2 from 8192 robots per GPU)")
     ap.add_argument("--pipelines", type=int, default=0,
                     help="qp workload: consecutive steps are independent batches (cold start, nothing carried over), so step i goes to "
                          "pipeline i %% P, each with its own streams and output buffers, and the load phase of one batch overlaps the "
@@ -482,7 +482,8 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     # `--streams 2`: the batch is cut into two independent halves, each its own pipeline on its own HIP stream.
     # Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
     n_streams = args.streams if args.streams else (2 if B >= 8192 and B % 2 == 0 else 1)
-    parts = [(first, B)] if n_streams == 1 else [(first, B // 2), (first + B // 2, B - B // 2)]
+    cuts = [B * k // n_streams for k in range(n_streams + 1)]
+    parts = [(first + cuts[k], cuts[k + 1] - cuts[k]) for k in range(n_streams)]
     ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
     pipes = []
     kin = wca.KinModel(wca.synth.icub_like_model()) if kin_mode else None
