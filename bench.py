@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--streams", type=int, choices=[0, 1, 2, 3, 4], default=0,
                     help="qp workload: 0/1 = the MPC and the IK of a step are ONE launch (wcqp_qp_enqueue_steps, both on one stream: "
                          "default); 2 = two launches on two streams.  tick workload: robot groups, each with a pipeline and a stream of its own "
-                         "(0 = 2 from 8192 robots per GPU)")
+                         "(0 = 2, or 3 with per-tick kinematics, from 8192 robots per GPU)")
     ap.add_argument("--pipelines", type=int, default=0,
                     help="qp workload: consecutive steps are independent batches (cold start, nothing carried over), so step i goes to "
                          "pipeline i %% P, each with its own streams and output buffers, and the load phase of one batch overlaps the "
@@ -481,7 +481,9 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     vmax = args.ik_vmax if args.tick_tables else max(args.ik_vmax, 1.0)     # the walking robot needs up to ~1 rad/s of joint velocity
     # `--streams 2`: the batch is cut into two independent halves, each its own pipeline on its own HIP stream.
     # Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
-    n_streams = args.streams if args.streams else (2 if B >= 8192 and B % 2 == 0 else 1)
+    # robot groups, each a pipeline on a stream of its own: two halves with constant Jacobians, three thirds with the
+    # kinematics launch in the tick (56.3 -> 55.2 us per tick at 8192 robots; four buy nothing more)
+    n_streams = args.streams if args.streams else ((3 if kin_mode else 2) if B >= 8192 else 1)
     cuts = [B * k // n_streams for k in range(n_streams + 1)]
     parts = [(first + cuts[k], cuts[k + 1] - cuts[k]) for k in range(n_streams)]
     ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
@@ -547,7 +549,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
                          % ("forward kinematics + Jacobians + support polygon at the integrated joint state -> " if kin_mode else "constant Jacobians, ",
                             args.ik_form, vmax, B, "hipGraph replay" if graph else "plain launches")),
             "batch_per_gpu": B, "global_batch": B * world, "horizon": 50, "dof": 23, "ticks": args.steps, "per_tick_kinematics": kin_mode,
-            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s" % (world, "; two half-batches on two HIP streams" if len(pipes) > 1 else ""),
+            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s" % (world, ("; %d robot groups on %d HIP streams" % (len(pipes), len(pipes))) if len(pipes) > 1 else ""),
         },
         "roofline": {"bound": "hbm", "kernel": "whole tick (%s)" % launches, "achieved": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
