@@ -117,12 +117,12 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* qpos, const double* __restrict__ state,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
-                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td, double (*smem)[PER_INST])
+                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td, double (*smem)[PER_INST], int blk)
 {
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int j = lane & 15;
-    const long inst_raw = (long)blockIdx.x * 4 + grp;
+    const long inst_raw = (long)blk * 4 + grp;
     const bool live = inst_raw < batch;
     const long inst = live ? inst_raw : (long)batch - 1;
     double* S = smem[grp];
@@ -988,7 +988,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             if (j == 0) wcqp_tick::tick_post_instance(td, i_, tick_now, ik_ok);
         }
         // advanceReferenceSignals (WalkingModule.cpp:816): the next tick reads the other copy of the tick index
-        if (blockIdx.x == 0 && lane == 0) td.tick2[1 - td.phase] = tick_now + 1;
+        if (blk == 0 && lane == 0) td.tick2[1 - td.phase] = tick_now + 1;
     }
     if (ferr_out) {
         // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401) with nu = (v_base, dq) and
@@ -1046,7 +1046,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
-    ik4_body<TICK>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem);
+    ik4_body<TICK>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem, (int)blockIdx.x);
 }
 
 // Both QPs of a batch of robot-ticks in ONE launch (wcqp_qp_enqueue_steps, a record whose two calls go to the same
@@ -1069,12 +1069,16 @@ void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                     double* __restrict__ ferr_out, int* __restrict__ iters_out, int ik_blocks, MpcPairArgs m)
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
-    if ((int)blockIdx.x >= ik_blocks) {
+    // IK workgroups first: they are the long ones.  (Alternating the two kinds in dispatch order was measured: the MPC waves
+    // then take slots from IK waves that have not started yet - 17.7 vs 14.5 us at 4096 robots, 158 vs 116 us at 65536.)
+    const bool is_mpc = (int)blockIdx.x >= ik_blocks;
+    const int blk = is_mpc ? (int)blockIdx.x - ik_blocks : (int)blockIdx.x;
+    if (is_mpc) {
         static_assert(wcqp_mpc::kInstPerWave * WCQP_HULL_ROWS * 4 <= 4 * PER_INST, "the hull rows fit the IK's LDS");
         double (*s_hull)[WCQP_HULL_ROWS][4] = reinterpret_cast<double (*)[WCQP_HULL_ROWS][4]>(&smem[0][0]);
         const int lane = threadIdx.x;
         const int sub = lane / wcqp_mpc::kLanesPerInstance, t = lane % wcqp_mpc::kLanesPerInstance;
-        const long inst_raw = (long)((int)blockIdx.x - ik_blocks) * wcqp_mpc::kInstPerWave + sub;
+        const long inst_raw = (long)blk * wcqp_mpc::kInstPerWave + sub;
         const bool live = inst_raw < batch;
         const long inst = live ? inst_raw : (long)batch - 1;
         const double2* rp = reinterpret_cast<const double2*>(m.ref) + inst * m.ref_len;
@@ -1090,7 +1094,7 @@ void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         }
         return;
     }
-    ik4_body<false>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem);
+    ik4_body<false>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem, blk);
 }
 
 }  // namespace
