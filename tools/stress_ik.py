@@ -9,9 +9,9 @@ for seed in (101, 202):
     b = wca.synth.synth_ik_batch(B, seed=seed)
     args = (b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
     for form, vmax in ((wca.IK_FORM_QPOASES, 0.5), (wca.IK_FORM_QPOASES, 0.3), (wca.IK_FORM_QPOASES, 0.2), (wca.IK_FORM_QPOASES, 0.12), (wca.IK_FORM_OSQP, 0.3)):
-        outs = {a: wca.IkSolver(form=form, v_max=vmax, algorithm=a).solve_host(*args) for a in (4, 3, 1)}
+        outs = {a: wca.IkSolver(form=form, v_max=vmax, algorithm=a).solve_host(*args) for a in (5, 4, 3)}
         ref = outs[3]
-        for a in (4, 1):
+        for a in (5, 4):
             o = outs[a]
             both = (o["status"] == 0) & (ref["status"] == 0)
             rep.append(dict(seed=seed, form=int(form), vmax=vmax, alg=a, n=B, solved=int((o["status"] == 0).sum()), solved_ref=int((ref["status"] == 0).sum()),
