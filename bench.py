@@ -224,12 +224,11 @@ def main():
         region - and the time after the device-wide synchronize that follows: on this ROCm stack the first
         hipDeviceSynchronize after a burst of launches costs the host 55-75 us with the device already idle
         (tools/sync_cost.py; it is 4 us on a quiet process), which is 20 % of a 20-step region and no part of the steps."""
-        evs = [torch.cuda.Event() for _ in all_streams]
+        evs = barrier.events                            # created once: the timed region pays for the records only
         for e, st_ in zip(evs, all_streams):
             e.record(st_)
-        if not os.environ.get("WCQP_BENCH_NOPOLL"):
-            while not all(e.query() for e in evs):      # polled: a blocking wait wakes up ~50 us late
-                pass
+        while not all(e.query() for e in evs):          # polled: a blocking wait wakes up ~50 us late
+            pass
         for e in evs:
             e.synchronize()
         t_done = time.perf_counter()
@@ -240,6 +239,7 @@ def main():
         torch.cuda.synchronize(dev)
         return t_done, t_sync
 
+    barrier.events = [torch.cuda.Event() for _ in all_streams]
     # the inputs and the zero-filled outputs were enqueued on the default stream: the MPC stream starts behind them
     for st_ in all_streams:
         if st_ is not stream:
