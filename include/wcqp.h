@@ -384,7 +384,9 @@ typedef struct wcqp_tick_outputs {  /* HOST pointers, any may be NULL */
     double* dq_log;             /* [log_ticks][B][dof]                                         */
     double* q_des;              /* [B][dof]                                                    */
     double* dcm; double* com;   /* [B][2]                                                      */
-    int64_t* mpc_fail; int64_t* ik_fail;   /* [B] ticks whose QP did not end SOLVED            */
+    int64_t* mpc_fail; int64_t* ik_fail;   /* [B] ticks whose QP did not end SOLVED; a robot whose IK failed once is
+                                              stopped (the reference's updateModule returns false, WalkingModule.cpp:723-739):
+                                              dq = 0 from then on and every further tick counts                      */
     int64_t* hot_try; int64_t* hot_hit;    /* [B] ticks on which the previous active set was tried / accepted (IK hot start) */
     int32_t* tick;              /* ticks executed so far                                       */
 } wcqp_tick_outputs;

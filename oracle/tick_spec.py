@@ -174,6 +174,11 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
             Jsrc = {n: J_now[i][n][None] for n in ("J_left", "J_right", "J_neck", "J_com")} if use_kin else \
                    {n: data[n][i:i + 1] for n in ("J_left", "J_right", "J_neck", "J_com")}
             one = dict(q=q_des[i:i + 1], state=s[None, :], **Jsrc)
+            if ik_fail[i] > 0:
+                # a robot whose IK failed once is stopped: updateModule returns false and the module closes
+                # (WalkingModule.cpp:414-416, 723-739); it keeps dq = 0 and every further tick counts as failed
+                ik_fail[i] += 1
+                continue
             try:
                 dq[i] = qs.ik_exact(ik_params, qs.ik_inputs_from_batch(one, 0), ik_form)["dq"]
             except qs.QPOracleError:

@@ -70,7 +70,7 @@ def test_tick_pipeline_long_run_is_stable_and_shard_invariant(wca):
         return pipe.download()
     full = run(d, 0, B)
     assert full["tick"] == T and full["mpc_fail"].sum() == 0
-    assert full["ik_fail"].sum() <= 0.001 * B * T
+    assert (full["ik_fail"] > 0).sum() <= 0.002 * B + 1      # robots that stopped (a failed IK stops a robot for good)
     # an IK the device did not solve must be one the exact oracle cannot solve either:
     # replay every failing robot (at most three) through oracle/tick_spec.py and compare the failure counts
     from oracle import tick_spec as ts, qp_spec as qs

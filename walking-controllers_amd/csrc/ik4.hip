@@ -135,9 +135,12 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 
     int tick_now = 0;
     unsigned prev_lo = 0u, prev_up = 0u;            // hot start: the previous tick's active bounds of this instance
+    bool stopped = false;                           // tick pipeline: the robot's IK failed on an earlier tick (tick_device.h)
     if constexpr (TICK) {
         tick_now = td.tick2[td.phase];
         if (td.hot_start && alo_out && aup_out) { prev_lo = alo_out[inst]; prev_up = aup_out[inst]; }
+        stopped = wcqp_tick::tick_robot_stopped(td, (int)inst);
+        if (stopped) { prev_lo = 0u; prev_up = 0u; }
     }
 
     WCQP_STAMP(0);
@@ -470,7 +473,8 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     double sig0 = 0.0, sig1 = 0.0;
     const bool bnd1 = var1;
     lo1 = bnd1 ? lo1 : -inf; hi1 = bnd1 ? hi1 : inf;
-    const bool need = !osqp_form && (fmax(nu0 - hi0, lo0 - nu0) > tol || (bnd1 && fmax(nu1 - hi1, lo1 - nu1) > tol));
+    // a stopped robot's result is not used: its (typically long, infeasible) active-set walk would only be the launch's tail
+    const bool need = !stopped && !osqp_form && (fmax(nu0 - hi0, lo0 - nu0) > tol || (bnd1 && fmax(nu1 - hi1, lo1 - nu1) > tol));
     const unsigned long long need_m = __ballot(need);
     if (((need_m >> (16 * grp)) & 0xffffull) != 0ull && st_code == WCQP_STATUS_SOLVED) {
         // Goldfarb-Idnani dual active set on columns of P = I - C' M^-1 C (see ik3.hip phase 5 for the scheme;

@@ -140,10 +140,15 @@ __device__ __forceinline__ void tick_glue_height(const TickDev& d, int i, double
     if (d.kin_mode) { s[71] = d.com_h0[i]; s[74] = 0.0; }
     else { s[68] = d.com_height; s[71] = d.com_height; s[74] = 0.0; }
 }
+// A robot whose IK failed once is STOPPED: updateModule returns false on an unsolved QP-IK and the module closes
+// (WalkingModule.cpp:414-416, 723-739).  Here it keeps dq = 0 and every further tick counts as failed; ik_fail > 0 is the
+// flag (written only by tick_post_instance, and only on ticks whose joint update is zero anyway: no ordering is needed
+// between the lanes that read it and the lane that bumps it).
+__device__ __forceinline__ bool tick_robot_stopped(const TickDev& d, int i) { return d.ik_fail[i] > 0; }
 // joint jj of instance i after the IK of tick t: q <- Integrator(dq) (WalkingModule.cpp:741-744)
 __device__ __forceinline__ void tick_post_joint(const TickDev& d, int i, int t, int jj, bool ik_ok, double dq) {
     const size_t g = (size_t)i * kDof + jj;
-    const double v = ik_ok ? dq : 0.0;
+    const double v = (ik_ok && !tick_robot_stopped(d, i)) ? dq : 0.0;
     d.q_des[g] += 0.5 * d.dT * (v + d.dq_prev[g]);
     d.dq_prev[g] = v;
     if (t < d.log_ticks) d.dq_log[(size_t)t * d.batch * kDof + g] = v;
@@ -152,7 +157,7 @@ __device__ __forceinline__ void tick_post_joint(const TickDev& d, int i, int t, 
 // (WalkingController::setConvexHullConstraint switches rows only when the pair changes,
 // …PredictiveController.cpp:369-374 — here the MPC kernel simply reads the row set this index selects)
 __device__ __forceinline__ void tick_post_instance(const TickDev& d, int i, int t, bool ik_ok) {
-    if (!ik_ok) d.ik_fail[i] += 1;
+    if (!ik_ok || tick_robot_stopped(d, i)) d.ik_fail[i] += 1;
     d.sel[i] = contact_code(t + 1, d.phase0[i], d.step_ticks, d.ds_ticks);
 }
 #endif
