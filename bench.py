@@ -482,8 +482,8 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     # `--streams 2`: the batch is cut into two independent halves, each its own pipeline on its own HIP stream.
     # Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
     # robot groups, each a pipeline on a stream of its own: two halves with constant Jacobians, three thirds with the
-    # kinematics launch in the tick (56.3 -> 55.2 us per tick at 8192 robots; four buy nothing more)
-    n_streams = args.streams if args.streams else ((3 if kin_mode else 2) if B >= 8192 else 1)
+    # kinematics launch in the tick up to 16384 robots (-2 % per tick at 8192; four buy nothing more; at 65536 three cost 14 %)
+    n_streams = args.streams if args.streams else ((3 if (kin_mode and B <= 16384) else 2) if B >= 8192 else 1)
     cuts = [B * k // n_streams for k in range(n_streams + 1)]
     parts = [(first + cuts[k], cuts[k + 1] - cuts[k]) for k in range(n_streams)]
     ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
