@@ -139,11 +139,13 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
 #pragma unroll
     for (int r = 0; r < kMaxRounds; ++r) up[r] = md->up[r][jc];
     double pose_in = 0.0;
-    int side = 0;
+    int side = 0, sel_code = 0, sel_done = 0;
     if constexpr (TICK) {
         if (i < 24) pose_in = state[inst * kStateLen + 24 + i];                  // desired poses of the two soles: p (3), R (9) each
         const int t_now = kt.tick2[kt.phase];
         side = ((t_now + kt.phase0[inst]) % (2 * kt.step_ticks)) / kt.step_ticks;     // 0: left is the stance foot
+        sel_code = kt.sel[inst];                 // for the hull rows at the very end: loaded here, not there
+        sel_done = kt.sel_built[inst];
     } else {
         if (i < 12) pose_in = base[inst * 12 + i];
     }
@@ -411,8 +413,8 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
         // from the DESIRED foot transforms (the planned footsteps, WalkingModule.cpp:609-613), entries 24..47 of the
         // pose block
         if (i == 0 && live) {
-            const int code = kt.sel[inst];
-            if (code != kt.sel_built[inst]) {
+            const int code = sel_code;
+            if (code != sel_done) {
                 const double* sd = state + inst * kStateLen;
                 double px[8], py[8];
                 int np = 0;
