@@ -12,11 +12,11 @@ instance cold-started.  Inputs are resident in HBM before the timed region start
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Consecutive steps are independent batches (cold start: nothing is carried from one step to the next), so up to
-batch 32768 - at the BASELINE batch a launch is one wave per SIMD that spends half its life waiting for its inputs - step i goes to
+Consecutive steps are independent batches (cold start: nothing is carried from one step to the next) and at the
+BASELINE batch a launch is one wave per SIMD that spends half its life waiting for its inputs, so step i goes to
 pipeline i % 3, each pipeline with its own streams and output buffers, and the input loads of one batch run under the
 arithmetic of the previous one (`--pipelines 1` for strictly one batch at a time).  The timed steps are handed to the
-library in one host call (`wcqp_qp_enqueue_steps`: the same two launches per step, without an FFI round trip each).
+library in one host call (`wcqp_qp_enqueue_steps`), which makes the MPC and the IK of a step ONE launch.
 Timed region: barrier + torch.cuda.synchronize() -> K steps -> every stream's completion event (hipEventSynchronize),
 MAX over ranks; the device-wide synchronize follows the clock (`ms_per_step_incl_device_sync` keeps it inside: on this
 ROCm stack that call costs the host 55-75 us with the device already idle, a fifth of a 20-step region).
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--pipelines", type=int, default=0,
                     help="qp workload: consecutive steps are independent batches (cold start, nothing carried over), so step i goes to "
                          "pipeline i %% P, each with its own streams and output buffers, and the load phase of one batch overlaps the "
-                         "arithmetic of the previous one; 0 = 3 for batches up to 32768 (one wave per SIMD per launch), else 1")
+                         "arithmetic of the previous one; 0 = 3 (1 with --exchange)")
     ap.add_argument("--horizon", type=int, default=50, help="qp workload: MPC horizon N (BASELINE: 50; the shipped controllerHorizon 2 s is N = 200: auxiliary line)")
     ap.add_argument("--input-sets", type=int, default=0, help="qp workload: distinct input sets visited round-robin (0 = enough for > 320 MB, at least 2)")
     ap.add_argument("--ik-jac", choices=["mixed", "auto", "general"], default="mixed",
@@ -132,7 +132,7 @@ def main():
     set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
     K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
-    P = args.pipelines if args.pipelines > 0 else (3 if (B <= 32768 and not (args.exchange and world > 1)) else 1)
+    P = args.pipelines if args.pipelines > 0 else (1 if (args.exchange and world > 1) else 3)
 
     def outputs():
         return dict(u0=torch.zeros(B, 2, dtype=torch.float64, device=dev), mstat=torch.zeros(B, dtype=torch.int32, device=dev),
