@@ -285,6 +285,39 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
     double aw[3];
     mat3_vec(Rw, ax, aw);
     WCQP_KSTAMP(4);
+    wcqp::wave_lds_fence();                   // FR is complete
+    // ---------------- Jacobian columns of the three frames: stored NOW, so that the stores drain under the moments and the
+    // CoM columns instead of all 22 store instructions leaving at the very end of the wave
+    if (live && i < 6 + dof) {
+        const int ncol = 6 + dof;
+        double e[3] = {0.0, 0.0, 0.0};
+        if (i < 6) e[i % 3] = 1.0;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const double* F = S + OFF_FR + f * 12;
+            double lin[3] = {0.0, 0.0, 0.0}, ang[3] = {0.0, 0.0, 0.0};
+            if (i < 3) {
+                lin[0] = e[0]; lin[1] = e[1]; lin[2] = e[2];
+            } else if (i < 6) {
+                const double d[3] = {F[9] - pb[0], F[10] - pb[1], F[11] - pb[2]};
+                cross3(e, d, lin);                           // column k of -S(p_f - p_b) = e_k x (p_f - p_b)
+                ang[0] = e[0]; ang[1] = e[1]; ang[2] = e[2];
+            } else if ((on_path >> f) & 1u) {
+                const double d[3] = {F[9] - pw[0], F[10] - pw[1], F[11] - pw[2]};
+                cross3(aw, d, lin);
+                ang[0] = aw[0]; ang[1] = aw[1]; ang[2] = aw[2];
+            }
+            if (f < 2) {
+                double* J = (f == 0 ? JL : JR) + inst * (6 * ncol);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { J[r * ncol + i] = lin[r]; J[(3 + r) * ncol + i] = ang[r]; }
+            } else {
+                double* J = JN + inst * (3 * ncol);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) J[r * ncol + i] = ang[r];        // the IK keeps the angular rows (setNeckJacobian)
+            }
+        }
+    }
     // link first moment {m c, m} of the own joint's link, and of the root link
     double e4[4] = {0.0, 0.0, 0.0, 0.0};
     if (is_joint) {
@@ -352,36 +385,11 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
     for (int k = 0; k < 3; ++k) ctot[k] = tot[k] * iM;
 
     WCQP_KSTAMP(5);
-    // ---------------- Jacobian columns ---------------------------------------------------------
+    // ---------------- CoM Jacobian columns (the frames' went out before the moments) ---------------
     if (live && i < 6 + dof) {
         const int ncol = 6 + dof;
         double e[3] = {0.0, 0.0, 0.0};
         if (i < 6) e[i % 3] = 1.0;
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            const double* F = S + OFF_FR + f * 12;
-            double lin[3] = {0.0, 0.0, 0.0}, ang[3] = {0.0, 0.0, 0.0};
-            if (i < 3) {
-                lin[0] = e[0]; lin[1] = e[1]; lin[2] = e[2];
-            } else if (i < 6) {
-                const double d[3] = {F[9] - pb[0], F[10] - pb[1], F[11] - pb[2]};
-                cross3(e, d, lin);                           // column k of -S(p_f - p_b) = e_k x (p_f - p_b)
-                ang[0] = e[0]; ang[1] = e[1]; ang[2] = e[2];
-            } else if ((on_path >> f) & 1u) {
-                const double d[3] = {F[9] - pw[0], F[10] - pw[1], F[11] - pw[2]};
-                cross3(aw, d, lin);
-                ang[0] = aw[0]; ang[1] = aw[1]; ang[2] = aw[2];
-            }
-            if (f < 2) {
-                double* J = (f == 0 ? JL : JR) + inst * (6 * ncol);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) { J[r * ncol + i] = lin[r]; J[(3 + r) * ncol + i] = ang[r]; }
-            } else {
-                double* J = JN + inst * (3 * ncol);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) J[r * ncol + i] = ang[r];        // the IK keeps the angular rows (setNeckJacobian)
-            }
-        }
         double lin[3] = {0.0, 0.0, 0.0};
         if (i < 3) {
             lin[0] = e[0]; lin[1] = e[1]; lin[2] = e[2];
