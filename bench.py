@@ -351,7 +351,7 @@ def main():
             "timed_region": "barrier + torch.cuda.synchronize() -> K steps -> completion events of every stream used (hipEventSynchronize), "
                             "MAX over ranks; the device-wide synchronize that follows adds %.0f us of host time with the device idle "
                             "(ms_per_step_incl_device_sync)" % (1e6 * (elapsed_sync - elapsed)),
-            "ms_per_step_incl_device_sync": 1e3 * elapsed_sync / args.steps,
+            "ms_per_step_incl_device_sync": 1e3 * elapsed_sync / args.steps, "value_incl_device_sync": total_qp / elapsed_sync,
             "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ("; MPC and IK of a step in one launch" if not exch else "")) + ("; %d independent batches in flight (step i -> pipeline i %% %d)" % (P, P) if P > 1 else ""),
         },
         # the dominant kernel of the timed region: the one-launch step (IK + MPC workgroups; algorithmic bytes = both QPs'
