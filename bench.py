@@ -79,6 +79,8 @@ def main():
                          "instances (one more, nearly empty, launch), general = the general kernel only")
     ap.add_argument("--tick-tables", action="store_true", help="tick workload: constant uploaded Jacobians and precomputed hull tables "
                     "(round-1 form) instead of per-tick kinematics")
+    ap.add_argument("--tick-dense-handoff", action="store_true", help="tick workload with kinematics: four dense Jacobians between the kinematics and the "
+                    "solve kernel instead of the compact per-joint records (A/B; same results)")
     ap.add_argument("--tick-cold-ik", action="store_true", help="tick workload: no IK hot start (every tick walks the active set from the unconstrained optimum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
@@ -418,6 +420,15 @@ def max_over_ranks(dist, torch, dev, value):
     return float(t.item())
 
 
+def sum_over_ranks(dist, torch, dev, value):
+    if dist is None:
+        return value
+    on = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def bench_kin(args, wca, torch, dist, dev, world, rank, B, first):
     """Auxiliary line: the kinematics kernel alone - Jacobians and poses of B robots per step.
     Not the BASELINE metric: `metric` says so; the roofline is the kernel's own (HBM: it is bound by the 4.4 KB it
@@ -478,7 +489,8 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     (constant uploaded Jacobians, precomputed hull tables; one launch per tick)."""
     T = args.steps + args.warmup
     kin_mode = not args.tick_tables
-    vmax = args.ik_vmax if args.tick_tables else max(args.ik_vmax, 1.0)     # the walking robot needs up to ~1 rad/s of joint velocity (DESIGN.md)
+    # the walking robots carry per-joint velocity limits (synth.WALK_VMAX: legs 1.5, torso and arms 0.3 rad/s - DESIGN.md 8.2)
+    vmax = args.ik_vmax if args.tick_tables else wca.synth.WALK_VMAX
     # `--streams 2`: the batch is cut into two independent halves, each its own pipeline on its own HIP stream.
     # Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
     # robot groups, each a pipeline on a stream of its own: two halves with constant Jacobians, three thirds with the
@@ -498,7 +510,8 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
         else:
             data = wca.synth.synth_tick_batch(cnt, T, first=f0)
             iks = wca.IkSolver(form=ik_form, v_max=vmax)
-        pp = wca.TickPipeline(cnt, T, wca.MpcSolver(horizon=50), iks, first=f0, kin=kin, ik_hot_start=not args.tick_cold_ik)
+        pp = wca.TickPipeline(cnt, T, wca.MpcSolver(horizon=50), iks, first=f0, kin=kin, ik_hot_start=not args.tick_cold_ik,
+                              kin_dense_handoff=args.tick_dense_handoff)
         pp.upload(data)
         pipes.append(pp)
     stream = torch.cuda.current_stream(dev)
@@ -532,7 +545,12 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
                  "ik_fail": np.concatenate([x["ik_fail"] for x in states]),
                  "hot_try": int(sum(x["hot_try"].sum() for x in states)), "hot_hit": int(sum(x["hot_hit"].sum() for x in states))}
     dev_ms = e0.elapsed_time(e1) / args.steps
-    value = 2 * B * world * args.steps / elapsed
+    # QP solves = 2 per robot-tick, minus the robot-ticks of STOPPED robots (a robot whose IK failed keeps dq = 0 and its
+    # active-set walk is skipped from then on: ik_fail counts the failing tick and every tick after it; the failing
+    # tick itself did walk, so it stays counted).  Ranks > 0 report through the same all-reduce as the time.
+    stopped_ticks = int(np.maximum(out_state["ik_fail"] - 1, 0).sum())
+    stopped_ticks_all = int(round(sum_over_ranks(dist, torch, dev, float(stopped_ticks))))
+    value = (2 * B * world * args.steps - stopped_ticks_all) / elapsed
     # algorithmic I/O of a tick (6296 B) + resident controller / plant state read and written; with per-tick
     # kinematics the Jacobians and actual poses are written by one kernel and read by the next (4464 B more)
     bytes_per_tick = 6296 + 2 * 8 * (2 * 10 + 23 * 3) + (4464 + 280 if kin_mode else 0)
@@ -544,10 +562,10 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": ("BASELINE configs[3]/[4] per GPU: receding-horizon robot-tick (%sDCM-MPC N=50 on the advancing "
-                         "reference window -> ZMP-CoM glue -> QP-IK 23 DoF %s form v_max=%.2f -> joint integration), "
+                         "reference window -> ZMP-CoM glue -> QP-IK 23 DoF %s form v_max=%s -> joint integration), "
                          "B=%d robots, %s, contact pair changes every 70-110 ticks; 2 QP solves per robot-tick"
                          % ("forward kinematics + Jacobians + support polygon at the integrated joint state -> " if kin_mode else "constant Jacobians, ",
-                            args.ik_form, vmax, B, "hipGraph replay" if graph else "plain launches")),
+                            args.ik_form, ("%.2f" % vmax) if args.tick_tables else "legs 1.5 / upper body 0.3", B, "hipGraph replay" if graph else "plain launches")),
             "batch_per_gpu": B, "global_batch": B * world, "horizon": 50, "dof": 23, "ticks": args.steps, "per_tick_kinematics": kin_mode,
             "parallelism": "batch sharded over %d GPU(s), no data-path collective%s" % (world, ("; %d robot groups on %d HIP streams" % (len(pipes), len(pipes))) if len(pipes) > 1 else ""),
         },
@@ -556,6 +574,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
                      "traffic": None, "avg_launch_ms": dev_ms, "algorithmic_bytes_per_launch": bytes_per_tick * B},
         "solved": {"ticks_executed": out_state["tick"], "mpc_fail": int(out_state["mpc_fail"].sum()),
                    "ik_fail": int(out_state["ik_fail"].sum()), "robots_with_ik_fail": int((out_state["ik_fail"] > 0).sum()), "of": B * T,
+                   "stopped_robot_ticks_not_counted": stopped_ticks_all,
                    # IK hot start: robot-ticks on which the previous tick's active bounds were tried first / accepted
                    "ik_hot_start_tried": out_state["hot_try"], "ik_hot_start_accepted": out_state["hot_hit"],
                    "ik_hot_start_hit_rate": (out_state["hot_hit"] / out_state["hot_try"]) if out_state["hot_try"] else None},

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WCQP_VERSION 201
+#define WCQP_VERSION 300
 
 /* return codes */
 #define WCQP_OK              0
@@ -364,6 +364,13 @@ typedef struct wcqp_tick_params {
     int32_t use_kinematics;
     wcqp_kin_params kin;
     double  foot_rect[8];       /* corners (x, y) x 4 of the foot rectangle in the foot frame (foot_size, cpp:295-303) */
+    /* Per-tick kinematics hand the IK of the same tick its Jacobians through device memory.  By default (0) that hand-off
+     * is COMPACT whenever every joint lies on the path of at most one of the three frames (left sole, right sole, neck - true
+     * of a humanoid whose legs and torso branch at the root link): per joint its CoM column and its column of that ONE frame
+     * Jacobian, plus the three vectors p_frame - p_base that make up the base blocks [I -S(p); 0 I] - 1.4 KB per robot
+     * instead of the 4.4 KB of four dense Jacobians, ~70 % of which are structural zeros.  1 = dense Jacobians (the layouts
+     * of wcqp_kin_jacobians_* / wcqp_ik_solve_*); same results. */
+    int32_t kin_dense_handoff;
 } wcqp_tick_params;
 
 typedef struct wcqp_tick_inputs {   /* HOST pointers, copied at upload */

@@ -121,27 +121,19 @@ def _walk_scenario(wca, B, T, first=0):
     return kin, wca.synth.synth_walk_batch(B, T, poses, kb, first=first)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("ik_algorithm", [0, 4], ids=["kin+fused_solve", "kin+mpc+ik"])
-def test_tick_pipeline_with_per_tick_kinematics_matches_cpu_restatement(wca, qs, ik_algorithm):
-    """SURVEY 8f-4 inside the tick: every tick evaluates the forward kinematics at the integrated joint
-    state with the base anchored at the stance foot, hands four fresh MIXED Jacobians and the actual poses to the IK
-    (WM/src/WalkingModule.cpp:715, 396-410) and rebuilds the support polygon from the foot poses on a contact change
-    (...PredictiveController.cpp:364-435).  150 closed-loop ticks against oracle/tick_spec.py (kin_spec + hull_spec +
-    the exact QP solvers) at 1e-9; failures (an over-stretched leg makes the IK infeasible) must be the SAME ticks."""
+def _kin_tick_against_oracle(wca, qs, B, T, vmax, ik_algorithm, dense_handoff=False, graphs=(False, True)):
     from oracle import tick_spec as ts
-    B, T, vmax = 12, 150, 0.6          # tight enough for the limits to bind on this dozen of robots
     p = ts.TickParams()
     kin, d = _walk_scenario(wca, B, T)
     model = wca.synth.icub_like_model()
-    ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax * np.ones(23), joint_reg_deg=wca.synth.WALK_POSTURE_DEG.copy()),
+    vmax = np.broadcast_to(np.asarray(vmax, float), (23,)).copy()
+    ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax, joint_reg_deg=wca.synth.WALK_POSTURE_DEG.copy()),
                        kin_model=model, foot_rect=wca.synth.FOOT_RECT)
     assert ref["mpc_fail"].sum() == 0
-    # the Jacobians really change: the joints travel
-    assert np.abs(ref["q_des"] - d["q0"]).max() > 0.05
-    for use_graph in (False, True):
+    outs = []
+    for use_graph in graphs:
         ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm, joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
-        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik, log_ticks=T, kin=kin)
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik, log_ticks=T, kin=kin, kin_dense_handoff=dense_handoff)
         pipe.upload(d)
         pipe.run(T, use_graph=use_graph)
         out = pipe.download()
@@ -150,11 +142,58 @@ def test_tick_pipeline_with_per_tick_kinematics_matches_cpu_restatement(wca, qs,
         assert np.abs(out["u0_log"] - ref["u0_log"]).max() <= 1e-9
         assert np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8
         assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9
-        assert np.abs(out["dcm"] - ref["dcm"]).max() <= 1e-9
-        if not use_graph:
-            eager = out
+        assert np.abs(out["dcm"] - ref["dcm"]).max() <= 1e-9 and np.abs(out["com"] - ref["com"]).max() <= 1e-9
+        outs.append(out)
+    return d, ref, outs, vmax
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["kin+fused_solve", "kin+fused_solve,dense_handoff", "kin+mpc+ik"])
+def test_tick_pipeline_with_per_tick_kinematics_matches_cpu_restatement(wca, qs, variant):
+    """SURVEY 8f-4 inside the tick: every tick evaluates the forward kinematics at the integrated joint state with the base
+    anchored at the stance foot and hands fresh MIXED Jacobians and the actual poses to the IK
+    (WM/src/WalkingModule.cpp:715, 396-410) - as the compact per-joint records of the tick's own hand-off (default), as four
+    dense Jacobians (`kin_dense_handoff`), or through the general 16-lane kernel with a stand-alone MPC launch (algorithm 4);
+    the support polygons come from the desired foot poses (...PredictiveController.cpp:364-435).  150 closed-loop ticks against
+    oracle/tick_spec.py (kin_spec + hull_spec + the exact QP solvers) at 1e-9, graph replay == plain launches bitwise, no robot fails."""
+    alg = 4 if variant == "kin+mpc+ik" else 0
+    d, ref, (eager, out), vmax = _kin_tick_against_oracle(wca, qs, 12, 150, wca.synth.WALK_VMAX, alg, dense_handoff="dense" in variant)
+    assert ref["ik_fail"].sum() == 0                       # the walk scenario does not fall (DESIGN.md 8.2)
+    assert np.abs(ref["q_des"] - d["q0"]).max() > 0.05     # the Jacobians really change: the joints travel
     assert np.array_equal(out["u0_log"], eager["u0_log"]) and np.array_equal(out["dq_log"], eager["dq_log"])   # graph == eager, bitwise
-    assert np.abs(ref["dq_log"]).max() == pytest.approx(vmax, abs=1e-12)        # velocity limits really bind
+    assert (np.abs(np.abs(ref["dq_log"]) - vmax) < 1e-12).any()        # velocity limits really bind
+
+
+@pytest.mark.gpu
+def test_compact_and_dense_kinematics_handoff_agree(wca):
+    """The compact kinematics -> IK hand-off carries exactly the non-zero entries of the four Jacobians: both forms of the
+    tick give the same trajectories (the IK sees the same numbers; only exact zeros differ in how they are formed)."""
+    B, T = 256, 64
+    kin, d = _walk_scenario(wca, B, T)
+    res = []
+    for dense in (False, True):
+        ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=wca.synth.WALK_VMAX, joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik, log_ticks=T, kin=kin, kin_dense_handoff=dense)
+        pipe.upload(d); pipe.run(T, use_graph=True)
+        res.append(pipe.download())
+    a, b = res
+    assert a["ik_fail"].sum() == 0 and b["ik_fail"].sum() == 0
+    assert np.array_equal(a["u0_log"], b["u0_log"])
+    assert np.abs(a["dq_log"] - b["dq_log"]).max() <= 1e-12 and np.abs(a["q_des"] - b["q_des"]).max() <= 1e-12
+
+
+@pytest.mark.gpu
+def test_a_robot_whose_ik_fails_is_stopped_like_the_oracle(wca, qs):
+    """The failure path (WM/src/WalkingModule.cpp:723-739: updateModule returns false on an unsolved QP-IK): with joint
+    velocity limits too tight for the pelvis' change of sides (0.45 rad/s on every joint) some robots' IK becomes infeasible
+    in double support; the device stops exactly those robots on exactly those ticks (dq = 0 from then on), as
+    oracle/tick_spec.py does."""
+    d, ref, outs, vmax = _kin_tick_against_oracle(wca, qs, 10, 130, 0.45, 0, graphs=(True,))
+    assert (ref["ik_fail"] > 0).sum() >= 1 and (ref["ik_fail"] == 0).sum() >= 1
+    stopped = np.flatnonzero(ref["ik_fail"] > 0)
+    first = 130 - ref["ik_fail"][stopped]
+    for i, t0 in zip(stopped, first):
+        assert np.all(outs[0]["dq_log"][t0:, i] == 0.0)
 
 
 @pytest.mark.gpu

@@ -96,7 +96,8 @@ class TickParams(C.Structure):
                 ("step_ticks", C.c_int32), ("ds_ticks", C.c_int32),
                 ("k_com", C.c_double), ("k_zmp", C.c_double), ("noise", C.c_double), ("seed", C.c_uint64),
                 ("mpc", MpcParams), ("ik", IkParams),
-                ("ik_cold_start_only", C.c_int32), ("use_kinematics", C.c_int32), ("kin", KinParams), ("foot_rect", C.c_double * 8)]
+                ("ik_cold_start_only", C.c_int32), ("use_kinematics", C.c_int32), ("kin", KinParams), ("foot_rect", C.c_double * 8),
+                ("kin_dense_handoff", C.c_int32)]
 
 
 class TickInputs(C.Structure):
@@ -358,7 +359,7 @@ class TickPipeline:
 
     def __init__(self, batch, max_ticks, mpc: MpcSolver, ik: IkSolver, first=0, log_ticks=0,
                  step_ticks=180, ds_ticks=110, k_com=9.0, k_zmp=3.0, noise=1e-4, seed=99,
-                 kin: "Optional[KinModel]" = None, foot_rect=None, ik_hot_start: bool = True):
+                 kin: "Optional[KinModel]" = None, foot_rect=None, ik_hot_start: bool = True, kin_dense_handoff: bool = False):
         """kin: a KinModel -> per-tick kinematics (Jacobians, actual poses and hull rows rebuilt every tick from the
         integrated joint state with the base anchored at the stance foot; upload() then ignores J_* / hull_tab_*)."""
         self.batch, self.max_ticks, self.log_ticks, self.dof = batch, max_ticks, log_ticks, ik.dof
@@ -368,7 +369,7 @@ class TickPipeline:
             foot_rect = FOOT_RECT
         self.params = TickParams(batch, first, max_ticks, log_ticks, step_ticks, ds_ticks, k_com, k_zmp, noise, seed,
                                  mpc.params, ik.params, int(not ik_hot_start), int(self.use_kin), kin.params if kin is not None else KinParams(),
-                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)))
+                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(bool(kin_dense_handoff)))
         self._h = C.c_void_p()
         check(lib().wcqp_tick_create(C.byref(self.params), C.byref(self._h)), "wcqp_tick_create")
         self._keep = None

@@ -27,7 +27,35 @@ __global__ void hull_from_feet_kernel(int batch, const double* __restrict__ rect
     hull_nc[inst] = wcqp_hull::hull_rows(px, py, np, hull_A + (size_t)inst * 16, hull_b + (size_t)inst * 8);
 }
 
+// The tick pipeline with per-tick kinematics: the three row sets (left foot, right foot, both in contact) of every robot
+// from the DESIRED foot poses in its pose block (entries 24..35 left, 36..47 right).  One thread per (robot, contact pair).
+struct RectArg { double v[8]; };
+__global__ void hull_tables_kernel(int batch, RectArg rect, const double* __restrict__ state, int state_len,
+                                   double* __restrict__ tab_A, double* __restrict__ tab_b, int* __restrict__ tab_nc) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= batch * 3) return;
+    const int inst = g / 3, code = g % 3;
+    const double* sd = state + (size_t)inst * state_len;
+    double px[8], py[8];
+    int np = 0;
+    if (code == 0 || code == 2) wcqp_hull::foot_points(rect.v, sd + 24, px, py, np);
+    if (code == 1 || code == 2) wcqp_hull::foot_points(rect.v, sd + 36, px, py, np);
+    tab_nc[g] = wcqp_hull::hull_rows(px, py, np, tab_A + (size_t)g * 16, tab_b + (size_t)g * 8);
+}
+
 }  // namespace
+
+namespace wcqp {
+int hull_tables_from_state(int batch, const double* foot_rect_host, const double* state_dev, int state_len,
+                           double* tab_A, double* tab_b, int* tab_nc, hipStream_t stream) {
+    if (batch < 1 || !foot_rect_host || !state_dev || !tab_A || !tab_b || !tab_nc) return WCQP_E_INVALID;
+    RectArg r;
+    for (int k = 0; k < 8; ++k) r.v[k] = foot_rect_host[k];
+    hipLaunchKernelGGL(hull_tables_kernel, dim3((batch * 3 + 127) / 128), dim3(128), 0, stream, batch, r, state_dev, state_len, tab_A, tab_b, tab_nc);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+}  // namespace wcqp
 
 extern "C" {
 

@@ -109,7 +109,7 @@ __device__ __forceinline__ void swap16(double& a, double& b) {
 __device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 
-template <bool TICK>
+template <bool TICK, bool COMPACT = false>
 __device__ __forceinline__
 void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -153,18 +153,14 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     bool osqp_form;
     double k_pos_foot, k_att_foot, k_pos_com, kap;
     int fast_ok;
-    // tick pipeline: this tick's DCM-MPC on the same 16 lanes (what mpc_condensed_kernel does as a launch of its
-    // own elsewhere): window [t, t+N] of the instance's DCM trajectory, hull rows of the current contact pair,
-    // x0 = measured DCM, u_prev = previous output.  Its result stays in registers for the glue below.
-    double mpc_ux = 0.0, mpc_uy = 0.0;
-    int mpc_st = WCQP_STATUS_SOLVED;
-    if constexpr (TICK) {
-        const double2* rp = reinterpret_cast<const double2*>(td.ref_traj) + inst * td.traj_len + tick_now;
-        const long hset = inst * td.hull_sets + (td.hull_sets > 1 ? td.sel[inst] : 0);
-        unsigned mact; double mmar;
-        wcqp_mpc::mpc_row_solve(td.mpc, j, inst, td.dcm, rp, td.horizon + 1, td.u_prev, td.hull_tab_A, td.hull_tab_b, td.hull_tab_nc, hset,
-                                reinterpret_cast<double (*)[4]>(S + OFF_COL), mpc_ux, mpc_uy, mpc_st, mact, mmar);
-    }
+    // tick pipeline, SKEWED: this launch carries IK(t) and the MPC chain of tick t + 1 (tick_device.h).  The MPC chain
+    // MPC -> ZMP-CoM law -> LIPM plant does not depend on the IK, so the loads of MPC(t+1) are issued FIRST, the IK's loads
+    // behind them, and its arithmetic runs while the Jacobians are in flight; IK(t) reads what MPC(t) left in the hand-off
+    // record one launch ago (the first launch after an upload is primed by tick_mpc_prime_kernel, tick.hip).
+    wcqp_tick::TickMpcRegs mreg;
+    if constexpr (TICK) wcqp_tick::tick_mpc_issue(td, j, inst, tick_now + 1, mreg);
+    double2 cr0[5], cr1[5], cdv[5];        // COMPACT: the two joint records and the three vectors p_frame - p_base, as loaded
+    int ckind0 = 0, ckind1 = 0;
     {
         // the state block first: vmcnt retires in order, and the rhs phase only needs the state, so the 36
         // Jacobian loads stay in flight underneath it
@@ -175,19 +171,32 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
         q0 = qpos[inst * kDof + j];
         q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
-        double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0;
+        double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0, g_ok = 1.0, g_sw = 0.0, g_h0 = 0.0;
         if constexpr (TICK) {
-            if (live) {
-                const int i_ = (int)inst;
-                const bool mpc_ok = mpc_st == WCQP_STATUS_SOLVED || mpc_st == WCQP_STATUS_OUTSIDE_HULL;
-                if (j < 2) wcqp_tick::tick_glue_axis(td, i_, tick_now, j, mpc_ok, j == 0 ? mpc_ux : mpc_uy, g_com, g_pstar, g_vel);
-                if (j < 6) wcqp_tick::tick_glue_twist(td, i_, td.sel[i_], j, tick_now, g_twl, g_twr);
-                if (j == 0 && !mpc_ok) td.mpc_fail[i_] += 1;
-            }
+            // hand-off of MPC(t): desired CoM position / velocity (WalkingModule.cpp:686-695), the plant's CoM, did the MPC end usable
+            const double* hd = td.hand + ((size_t)(tick_now & 1) * td.batch + inst) * 10;
+            const int ja = j & 1;
+            g_pstar = hd[ja]; g_vel = hd[2 + ja]; g_com = hd[4 + ja]; g_ok = hd[8];
+            g_sw = td.swing_twist[inst * 6 + (j < 6 ? j : 0)];
+            g_h0 = td.kin_mode ? td.com_h0[inst] : td.com_height;
         }
         // the state / q loads above must ISSUE before the 36 column loads (vmcnt retires in order): hipcc otherwise sinks
         // one of them below the Jacobian loads and the state's LDS stores then wait for everything (vmcnt(0))
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (COMPACT) {
+            // compact kinematics -> IK hand-off (tick_device.h): one record per joint, [C lin3 | X ...], X = the joint's column of
+            // the one frame Jacobian it is on the path of; every other entry of the four Jacobians is a structural zero and the
+            // base blocks follow from the three vectors p_frame - p_base.  Five 16-byte loads per slot, whatever the record's
+            // length (what lies behind a short record is the next one: read and masked off), instead of 18 column loads.
+            // Unpacked into the dense columns further down, behind the MPC arithmetic that runs under these loads.
+            const double* jb = td.jcomp + inst * td.cstride;
+            const int off0 = wcqp_tick::compact_offset(td.cmaskL, td.cmaskR, td.cmaskN, j, ckind0);
+            const int off1 = wcqp_tick::compact_offset(td.cmaskL, td.cmaskR, td.cmaskN, var1 ? col1 : 0, ckind1);
+#pragma unroll
+            for (int m = 0; m < 5; ++m) { cr0[m] = ld2(jb + off0 + 2 * m); cr1[m] = ld2(jb + off1 + 2 * m); }
+#pragma unroll
+            for (int m = 0; m < 5; ++m) cdv[m] = ld2(jb + td.coff_d + 2 * m);
+        } else {
         const int fc0 = 6 + j;
         const int fc1 = var1 ? 22 + j : (base1 ? j - 8 : 0);
         const double* jl = JL + inst * (6 * kNV);
@@ -202,7 +211,19 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         for (int r = 0; r < 3; ++r) { a0[12 + r] = jc[r * kNV + fc0]; a1[12 + r] = jc[r * kNV + fc1]; }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { a0[15 + r] = jn[r * kNV + fc0]; a1[15 + r] = jn[r * kNV + fc1]; }
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TICK) {
+            // MPC(t+1), ZMP-CoM law and plant of tick t + 1 for the same four robots, while the Jacobians are on their way
+            wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL));
+            if (j < 6) {
+                const int code = wcqp_tick::contact_code(tick_now, mreg.phase0, td.step_ticks, td.ds_ticks);
+                const double tw = g_sw * wcqp_tick::swing_profile_at(td, mreg.phase0, tick_now);
+                g_twl = (code == 0 || code == 2) ? 0.0 : tw;
+                g_twr = (code == 1 || code == 2) ? 0.0 : tw;
+            }
+            if (live && j == 0 && g_ok == 0.0) td.mpc_fail[inst] += 1;
+        }
         // the scalar settings are read only now: in front of the column loads their (cold) scalar-cache misses would sit in
         // the same s_waitcnt as the Jacobian pointers and hold the 36 loads back
         osqp_form = prm->form == WCQP_IK_FORM_OSQP;
@@ -216,10 +237,27 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             wcqp::wave_lds_fence();
             if (j < 2) { if (!td.kin_mode) st[66 + j] = g_com; st[69 + j] = g_pstar; st[72 + j] = g_vel; }
             if (j < 6) { st[75 + j] = g_twl; st[81 + j] = g_twr; }
-            if (j == 0) wcqp_tick::tick_glue_height(td, (int)inst, st);
+            if (j == 0) { if (!td.kin_mode) st[68] = g_h0; st[71] = g_h0; st[74] = 0.0; }      // tick_glue_height
         }
     }
     wcqp::wave_lds_fence();
+    if constexpr (COMPACT) {
+        auto unpack = [&](const double2 (&r)[5], int kind, double (&a)[NROWS_IN]) {
+            const double x[6] = {r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, r[4].x};
+            const double mL = kind == 1 ? 1.0 : 0.0, mR = kind == 2 ? 1.0 : 0.0, mN = kind == 3 ? 1.0 : 0.0;
+#pragma unroll
+            for (int r_ = 0; r_ < 6; ++r_) { a[r_] = mL * x[r_]; a[6 + r_] = mR * x[r_]; }
+            a[12] = r[0].x; a[13] = r[0].y; a[14] = r[1].x;
+#pragma unroll
+            for (int r_ = 0; r_ < 3; ++r_) a[15 + r_] = mN * x[r_];
+        };
+        unpack(cr0, ckind0, a0);
+        unpack(cr1, ckind1, a1);
+        if (!var1) {
+#pragma unroll
+            for (int r_ = 0; r_ < NROWS_IN; ++r_) a1[r_] = 0.0;
+        }
+    }
 #ifdef WCQP_IK4_EXIT_AFTER_LOADS
     {   // diagnostic build: the launch up to the point where every input has landed
         double acc = q0 + q1 + st[j];
@@ -268,7 +306,25 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     WCQP_STAMP(2);
     // ---------------- phase 2: base blocks: MIXED pattern check, B_R - B_L, B_C - B_L ---------------------
     bool pat = true;
-    {
+    if constexpr (COMPACT) {
+        // the base blocks are B_f = -S(p_f - p_base) by construction (the kinematics kernel wrote the three vectors, not the
+        // blocks): column cm of B_f is e_cm x (p_f - p_base), the same products kin_jacobians_kernel forms for the dense columns
+        double* db = S + OFF_DB;
+        if (j >= 11 && j < 14) {
+            const int cm = j - 11;
+            const double e0 = cm == 0 ? 1.0 : 0.0, e1 = cm == 1 ? 1.0 : 0.0, e2 = cm == 2 ? 1.0 : 0.0;
+            double Bc[3][3];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const double d0 = f == 0 ? cdv[0].x : (f == 1 ? cdv[1].y : cdv[3].x);
+                const double d1 = f == 0 ? cdv[0].y : (f == 1 ? cdv[2].x : cdv[3].y);
+                const double d2 = f == 0 ? cdv[1].x : (f == 1 ? cdv[2].y : cdv[4].x);
+                Bc[f][0] = e1 * d2 - e2 * d1; Bc[f][1] = e2 * d0 - e0 * d2; Bc[f][2] = e0 * d1 - e1 * d0;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { db[r * 3 + cm] = Bc[1][r] - Bc[0][r]; db[9 + r * 3 + cm] = Bc[2][r] - Bc[0][r]; }
+        }
+    } else {
         double* db = S + OFF_DB;
         if (base1) {
             const int cb = j - 8;
@@ -989,7 +1045,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const int i_ = (int)inst;
             wcqp_tick::tick_post_joint(td, i_, tick_now, j, ik_ok, dq0);
             if (var1) wcqp_tick::tick_post_joint(td, i_, tick_now, col1, ik_ok, dq1);
-            if (j == 0) wcqp_tick::tick_post_instance(td, i_, tick_now, ik_ok);
+            if (j == 0 && (!ik_ok || stopped)) td.ik_fail[i_] += 1;       // tick_post_instance without the contact pair: the MPC part derives its own
         }
         // advanceReferenceSignals (WalkingModule.cpp:816): the next tick reads the other copy of the tick index
         if (blk == 0 && lane == 0) td.tick2[1 - td.phase] = tick_now + 1;
@@ -1039,7 +1095,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     }
 }
 
-template <bool TICK>
+template <bool TICK, bool COMPACT>
 __global__ __launch_bounds__(64, WCQP_IK4_WAVES)
 void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -1050,7 +1106,22 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
-    ik4_body<TICK>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem, (int)blockIdx.x);
+    ik4_body<TICK, COMPACT>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem, (int)blockIdx.x);
+}
+
+// The MPC chain of ONE tick for every robot, on its own: primes the skewed tick after an upload (MPC(0) has to have run
+// before the first fused launch, which carries IK(0) and MPC(1)).
+__global__ __launch_bounds__(64)
+void tick_mpc_prime_kernel(wcqp_tick::TickDev td, int t)
+{
+    __shared__ __attribute__((aligned(16))) double s_hull[4][WCQP_HULL_ROWS][4];
+    const int lane = threadIdx.x, grp = lane >> 4, j = lane & 15;
+    const long inst_raw = (long)blockIdx.x * 4 + grp;
+    const bool live = inst_raw < td.batch;
+    const long inst = live ? inst_raw : (long)td.batch - 1;
+    wcqp_tick::TickMpcRegs mreg;
+    wcqp_tick::tick_mpc_issue(td, j, inst, t, mreg);
+    wcqp_tick::tick_mpc_finish(td, j, inst, live, t, mreg, s_hull[grp]);
 }
 
 // Both QPs of a batch of robot-ticks in ONE launch (wcqp_qp_enqueue_steps, a record whose two calls go to the same
@@ -1126,7 +1197,7 @@ int ik4_launch(const IkDeviceParams* d_prm, int batch,
                const double* q, const double* state, double* dq, int* status,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
     const unsigned grid = (unsigned)((batch + 3) / 4);
-    hipLaunchKernelGGL(ik4_kernel<false>, dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+    hipLaunchKernelGGL((ik4_kernel<false, false>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
                        dq, status, alo, aup, ferr, iters, wcqp_tick::TickDev{});
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
@@ -1135,10 +1206,24 @@ int ik4_launch(const IkDeviceParams* d_prm, int batch,
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
                     const double* JL, const double* JR, const double* JN, const double* JC,
                     unsigned* alo, unsigned* aup, hipStream_t stream) {
-    if (!d_prm) return WCQP_E_INVALID;
+    if (!d_prm || !td.skew || !td.mst || !td.hand || !td.live_A || !td.live_b || !td.live_nc || !td.sel_built) return WCQP_E_INVALID;
+    if (td.compact && (!td.jcomp || td.cstride < 1)) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((td.batch + 3) / 4);
-    hipLaunchKernelGGL(ik4_kernel<true>, dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
-                       JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td);
+    if (td.compact)
+        hipLaunchKernelGGL((ik4_kernel<true, true>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
+                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td);
+    else
+        hipLaunchKernelGGL((ik4_kernel<true, false>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
+                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
+
+// MPC chain of tick t alone (see tick_mpc_prime_kernel)
+int ik4_launch_tick_prime(const wcqp_tick::TickDev& td, int t, hipStream_t stream) {
+    if (!td.skew || !td.mst || !td.hand) return WCQP_E_INVALID;
+    const unsigned grid = (unsigned)((td.batch + 3) / 4);
+    hipLaunchKernelGGL(tick_mpc_prime_kernel, dim3(grid), dim3(64), 0, stream, td, t);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }

@@ -389,7 +389,11 @@ int ik4_launch_pair(const IkDeviceParams* d_prm, int batch,
                     const wcqp_mpc::MpcDeviceConsts& c, const double* x0, const double* ref, int ref_len, const double* u_prev,
                     const double* hull_A, const double* hull_b, const int* hull_nc,
                     double* u0, int* mstatus, unsigned* mactive, double* mmargin, hipStream_t stream);
+// the base-eliminated kernel with the SKEWED tick fused in: IK(t) + post step of tick t and the MPC chain of tick t + 1
+// (tick_device.h); dense Jacobians, or the compact per-joint records of the tick's own kinematics kernel (td.compact)
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
                     const double* JL, const double* JR, const double* JN, const double* JC,
                     unsigned* alo, unsigned* aup, hipStream_t stream);
+// the MPC chain of tick t alone: primes the skewed tick after an upload
+int ik4_launch_tick_prime(const wcqp_tick::TickDev& td, int t, hipStream_t stream);
 }  // namespace wcqp_ik

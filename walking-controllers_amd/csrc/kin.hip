@@ -21,7 +21,6 @@
 #include <vector>
 #include "wcqp_internal.h"
 #include "tick_device.h"
-#include "hull_device.h"
 
 namespace {
 
@@ -90,9 +89,9 @@ constexpr int OFF_TW = 0, OFF_PS = 0, OFF_MC = 128, OFF_FR = 32 * 12, OFF_FRB = 
 static_assert(OFF_MC + 33 * 4 <= OFF_FR, "the first moments overlay the joint frames");
 
 #ifdef WCQP_KIN_STAMPS
-// diagnostic build: s_memtime at the phase boundaries, written through kt.hull_b (stand-alone launches only)
+// diagnostic build: s_memtime at the phase boundaries, written through kt.dbg (stand-alone launches only)
 #define WCQP_KSTAMP(k) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
-                            if (lane == 0 && kt.hull_b) reinterpret_cast<unsigned long long*>(kt.hull_b)[(size_t)blockIdx.x * 8 + (k)] = t__; } while (0)
+                            if (lane == 0 && kt.dbg) reinterpret_cast<unsigned long long*>(kt.dbg)[(size_t)blockIdx.x * 8 + (k)] = t__; } while (0)
 #else
 #define WCQP_KSTAMP(k) do { } while (0)
 #endif
@@ -100,8 +99,7 @@ static_assert(OFF_MC + 33 * 4 <= OFF_FR, "the first moments overlay the joint fr
 // small model facts as kernel arguments: no load in front of the first address computation
 struct KinShape { int dof, n_rounds, dfs_contig; };
 
-// TICK: the tick pipeline's per-tick call (WalkingModule.cpp:715, 396-410): base pose from the stance foot, support-polygon
-// rows rebuilt on a contact change (tick_device.h: KinTick)
+// TICK: the tick pipeline's per-tick call (WalkingModule.cpp:715, 396-410): base pose from the stance foot (tick_device.h: KinTick)
 //
 // The kernel is a LATENCY chain per wave (3-4 waves per SIMD, each about a thousand instructions between two trips to
 // memory), so every global load is issued at the top, in the order of use: q and the joint's constants, the
@@ -109,7 +107,11 @@ struct KinShape { int dof, n_rounds, dfs_contig; };
 #ifndef WCQP_KIN_WAVES
 #define WCQP_KIN_WAVES 3                       // waves per SIMD the register budget is set for (4: the tick variant spills)
 #endif
-template <bool TICK>
+// COMPACT (tick pipeline only): instead of the four dense Jacobians the kernel writes the tick-internal hand-off of
+// tick_device.h - per joint one record [C lin3 | X] with X = the joint's column of the ONE frame Jacobian whose path it is
+// on (every other entry of that column is a structural zero), and the three vectors p_frame - p_base the base blocks
+// [I -S(p); 0 I] are made of: 1.4 KB per robot instead of 4.4 KB, on the store side here and on the load side of the IK.
+template <bool TICK, bool COMPACT>
 __global__ __launch_bounds__(64, WCQP_KIN_WAVES)
 void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch,
                           const double* __restrict__ base, const double* __restrict__ q,
@@ -139,13 +141,11 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
 #pragma unroll
     for (int r = 0; r < kMaxRounds; ++r) up[r] = md->up[r][jc];
     double pose_in = 0.0;
-    int side = 0, sel_code = 0, sel_done = 0;
+    int side = 0;
     if constexpr (TICK) {
         if (i < 24) pose_in = state[inst * kStateLen + 24 + i];                  // desired poses of the two soles: p (3), R (9) each
         const int t_now = kt.tick2[kt.phase];
         side = ((t_now + kt.phase0[inst]) % (2 * kt.step_ticks)) / kt.step_ticks;     // 0: left is the stance foot
-        sel_code = kt.sel[inst];                 // for the hull rows at the very end: loaded here, not there
-        sel_done = kt.sel_built[inst];
     } else {
         if (i < 12) pose_in = base[inst * 12 + i];
     }
@@ -163,8 +163,9 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
     for (int k = 0; k < 3; ++k) fp[k] = md->frame_p[fi][k];
 
     unsigned on_path = 0u;                                 // bit f: this lane's joint is on the path root -> frame f
+    unsigned pm[3];
 #pragma unroll
-    for (int f = 0; f < 3; ++f) on_path |= ((md->path_mask[f] >> jc) & 1u) << f;
+    for (int f = 0; f < 3; ++f) { pm[f] = md->path_mask[f]; on_path |= ((pm[f] >> jc) & 1u) << f; }
     if (!is_joint) on_path = 0u;
     double rootc[3];
 #pragma unroll
@@ -288,6 +289,32 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
     wcqp::wave_lds_fence();                   // FR is complete
     // ---------------- Jacobian columns of the three frames: stored NOW, so that the stores drain under the moments and the
     // CoM columns instead of all 22 store instructions leaving at the very end of the wave
+    int ckind = 0;
+    double* crec = nullptr;                    // COMPACT: this lane's joint record
+    if constexpr (COMPACT) {
+        double* jb = kt.jcomp + inst * kt.cstride;
+        if (is_joint) crec = jb + wcqp_tick::compact_offset(pm[0], pm[1], pm[2], jc, ckind);
+        if (live && is_joint && ckind != 0) {
+            const double* F = S + OFF_FR + (ckind - 1) * 12;
+            const double d[3] = {F[9] - pw[0], F[10] - pw[1], F[11] - pw[2]};
+            double lin[3];
+            cross3(aw, d, lin);
+            if (ckind == 3) {                  // neck: the IK keeps the angular rows (setNeckJacobian)
+                crec[3] = aw[0];
+                *reinterpret_cast<double2*>(crec + 4) = make_double2(aw[1], aw[2]);
+            } else {
+                crec[3] = lin[0];
+                *reinterpret_cast<double2*>(crec + 4) = make_double2(lin[1], lin[2]);
+                *reinterpret_cast<double2*>(crec + 6) = make_double2(aw[0], aw[1]);
+                *reinterpret_cast<double2*>(crec + 8) = make_double2(aw[2], 0.0);
+            }
+        }
+        if (live && i < 2) {                   // p_left - p_base, p_right - p_base
+            const double* F = S + OFF_FR + i * 12;
+            double* dd = jb + kt.coff_d + 3 * i;
+            dd[0] = F[9] - pb[0]; dd[1] = F[10] - pb[1]; dd[2] = F[11] - pb[2];
+        }
+    } else
     if (live && i < 6 + dof) {
         const int ncol = 6 + dof;
         double e[3] = {0.0, 0.0, 0.0};
@@ -386,6 +413,20 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
 
     WCQP_KSTAMP(5);
     // ---------------- CoM Jacobian columns (the frames' went out before the moments) ---------------
+    if constexpr (COMPACT) {
+        if (live && is_joint) {
+            const double d[3] = {(mcs[0] - ms * pw[0]) * iM, (mcs[1] - ms * pw[1]) * iM, (mcs[2] - ms * pw[2]) * iM};
+            double lin[3];
+            cross3(aw, d, lin);
+            *reinterpret_cast<double2*>(crec) = make_double2(lin[0], lin[1]);
+            crec[2] = lin[2];
+            if (ckind == 0) crec[3] = 0.0;
+        }
+        if (live && i == 2) {                  // p_com - p_base
+            double* dd = kt.jcomp + inst * kt.cstride + kt.coff_d + 6;
+            dd[0] = ctot[0] - pb[0]; dd[1] = ctot[1] - pb[1]; dd[2] = ctot[2] - pb[2]; dd[3] = 0.0;
+        }
+    } else
     if (live && i < 6 + dof) {
         const int ncol = 6 + dof;
         double e[3] = {0.0, 0.0, 0.0};
@@ -416,23 +457,6 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
         if (i < 9) s[48 + i] = S[OFF_FR + 24 + i];            // neck orientation
         if (i < 3) s[66 + i] = ctot[i];                       // CoM position
     }
-    if constexpr (TICK) {
-        // setConvexHullConstraint: the rows change only when the contact pair does (cpp:369-374); they are built
-        // from the DESIRED foot transforms (the planned footsteps, WalkingModule.cpp:609-613), entries 24..47 of the
-        // pose block
-        if (i == 0 && live) {
-            const int code = sel_code;
-            if (code != sel_done) {
-                const double* sd = state + inst * kStateLen;
-                double px[8], py[8];
-                int np = 0;
-                if (code == 0 || code == 2) wcqp_hull::foot_points(kt.rect, sd + 24, px, py, np);
-                if (code == 1 || code == 2) wcqp_hull::foot_points(kt.rect, sd + 36, px, py, np);
-                kt.hull_nc[inst] = wcqp_hull::hull_rows(px, py, np, kt.hull_A + inst * 16, kt.hull_b + inst * 8);
-                kt.sel_built[inst] = code;
-            }
-        }
-    }
 }
 
 }  // namespace
@@ -462,14 +486,38 @@ int ensure_device(wcqp_kin_s* h) {
 
 namespace wcqp {
 int kin_prepare(wcqp_kin_t h) { return h ? ensure_device(h) : WCQP_E_INVALID; }
+// Layout of the compact kinematics -> IK hand-off for this tree (tick_device.h): the joints on the paths of the left sole,
+// the right sole and the neck, doubles per robot, offset of the three p_frame - p_base vectors.  false when a joint is on
+// more than one of the three paths (a record holds ONE frame's column): the tick then hands over dense Jacobians.
+bool kin_compact_layout(wcqp_kin_t h, unsigned masks[3], int* stride, int* off_d) {
+    if (!h) return false;
+    const KinDev& d = h->hd;
+    for (int f = 0; f < 3; ++f) masks[f] = d.path_mask[f];
+    if ((masks[0] & masks[1]) || (masks[0] & masks[2]) || (masks[1] & masks[2])) return false;
+    int kind = 0;
+    const int last = wcqp_tick::compact_offset(masks[0], masks[1], masks[2], d.dof - 1, kind);
+    const int end = last + (kind == 0 ? 4 : (kind == 3 ? 6 : 10));
+    *off_d = end;
+    // the IK reads five 16-byte pieces from a record's start whatever its length, and five from the vectors: keep both inside the block
+    const int need = (last + 10 > end + 10) ? last + 10 : end + 10;
+    *stride = (need + 1) & ~1;
+    return true;
+}
 int kin_enqueue_tick(wcqp_kin_t h, int batch, const wcqp_tick::KinTick& kt, const double* q,
                      double* J_left, double* J_right, double* J_neck, double* J_com, double* state, hipStream_t stream) {
-    if (!h || !h->d_model || batch < 1 || !state || !q || !J_left || !J_right || !J_neck || !J_com) return WCQP_E_INVALID;
-    if (!kt.tick2 || !kt.phase0 || !kt.sel || !kt.sel_built || !kt.hull_A || !kt.hull_b || !kt.hull_nc || kt.step_ticks < 1) return WCQP_E_INVALID;
+    if (!h || !h->d_model || batch < 1 || !state || !q) return WCQP_E_INVALID;
+    if (!kt.jcomp && (!J_left || !J_right || !J_neck || !J_com)) return WCQP_E_INVALID;
+    if (kt.jcomp && (kt.cstride < 1 || kt.coff_d < 0)) return WCQP_E_INVALID;
+    if (!kt.tick2 || !kt.phase0 || kt.step_ticks < 1) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((batch + 1) / 2);
-    hipLaunchKernelGGL(kin_jacobians_kernel<true>, dim3(grid), dim3(64), 0, stream, h->d_model,
-                       KinShape{h->hd.dof, h->hd.n_rounds, h->hd.dfs_contig}, batch, nullptr, q,
-                       J_left, J_right, J_neck, J_com, state, kt);
+    if (kt.jcomp)
+        hipLaunchKernelGGL((kin_jacobians_kernel<true, true>), dim3(grid), dim3(64), 0, stream, h->d_model,
+                           KinShape{h->hd.dof, h->hd.n_rounds, h->hd.dfs_contig}, batch, nullptr, q,
+                           J_left, J_right, J_neck, J_com, state, kt);
+    else
+        hipLaunchKernelGGL((kin_jacobians_kernel<true, false>), dim3(grid), dim3(64), 0, stream, h->d_model,
+                           KinShape{h->hd.dof, h->hd.n_rounds, h->hd.dfs_contig}, batch, nullptr, q,
+                           J_left, J_right, J_neck, J_com, state, kt);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }
@@ -559,9 +607,9 @@ int wcqp_kin_jacobians_device(wcqp_kin_t h, int32_t batch, const double* base, c
     const unsigned grid = (unsigned)((batch + 1) / 2);
     wcqp_tick::KinTick kt{};
 #ifdef WCQP_KIN_STAMPS
-    kt.hull_b = g_kin_dbg;
+    kt.dbg = g_kin_dbg;
 #endif
-    hipLaunchKernelGGL(kin_jacobians_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, h->d_model,
+    hipLaunchKernelGGL((kin_jacobians_kernel<false, false>), dim3(grid), dim3(64), 0, (hipStream_t)stream, h->d_model,
                        KinShape{h->hd.dof, h->hd.n_rounds, h->hd.dfs_contig}, batch, base, q,
                        J_left, J_right, J_neck, J_com, state, kt);
     WCQP_HIP_TRY(hipGetLastError());

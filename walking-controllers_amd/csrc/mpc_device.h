@@ -40,6 +40,70 @@ __device__ __forceinline__ int row_move(int v) { return __builtin_amdgcn_update_
 // mirror, which pair quads / octets whose lanes already agree
 #define WCQP_ROW_STEPS(X) X(0xB1) X(0x4E) X(0x141) X(0x140)
 
+// The reference window of one QP and its gain blocks, in registers: the loads are issued by mpc_window_loads and consumed
+// by mpc_row_partial, so a caller can put other loads (the tick kernel: the IK's Jacobians) behind them and run the MPC
+// arithmetic while those are in flight (vmcnt retires in order: what is issued first can be waited for first).
+// One pass: stages t, t+16, t+32, t+48 (covers N <= 63); longer horizons add looping passes (mpc_row_extra_passes).
+struct MpcLoads {
+    double2 r[4], g0[4], g1[4];
+};
+__device__ __forceinline__ void mpc_window_loads(const MpcDeviceConsts& c, int t, const double2* __restrict__ rp, int ref_len, MpcLoads& L)
+{
+    const double2* gp = reinterpret_cast<const double2*>(c.Gr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = t + k * kLanesPerInstance;
+        const int ic = i <= c.N ? i : c.N;                // clamped: stays in bounds, weight zeroed in mpc_row_partial
+        const int ir = ic < ref_len ? ic : ref_len - 1;   // MPCSolver.cpp:200-214 (constant tail)
+        L.r[k] = rp[ir];
+        L.g0[k] = gp[2 * ic]; L.g1[k] = gp[2 * ic + 1];
+    }
+}
+// this lane's partial sum of u0_unc from the loaded window (partial, extra passes, then mpc_row_add_state on lane 0: the
+// order of operations of mpc_row_solve, so the results are bit-identical)
+__device__ __forceinline__ void mpc_row_partial(const MpcDeviceConsts& c, int t, const MpcLoads& L, double& ux, double& uy) {
+    ux = 0.0; uy = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double m = (t + k * kLanesPerInstance) <= c.N ? 1.0 : 0.0;
+        ux = fma(m * L.g0[k].x, L.r[k].x, fma(m * L.g0[k].y, L.r[k].y, ux));
+        uy = fma(m * L.g1[k].x, L.r[k].x, fma(m * L.g1[k].y, L.r[k].y, uy));
+    }
+}
+// stages 64 .. N of a horizon longer than one pass (the shipped controllerHorizon: N = 200), loaded on the spot
+__device__ __forceinline__ void mpc_row_extra_passes(const MpcDeviceConsts& c, int t, const double2* __restrict__ rp, int ref_len, double& ux, double& uy) {
+    const double2* gp = reinterpret_cast<const double2*>(c.Gr);
+    for (int base = 4 * kLanesPerInstance; base <= c.N; base += 4 * kLanesPerInstance) {
+        double2 r[4], g0[4], g1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + t + k * kLanesPerInstance;
+            const int ic = i <= c.N ? i : c.N;
+            const int ir = ic < ref_len ? ic : ref_len - 1;
+            r[k] = rp[ir];
+            g0[k] = gp[2 * ic]; g1[k] = gp[2 * ic + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double m = (base + t + k * kLanesPerInstance) <= c.N ? 1.0 : 0.0;
+            ux = fma(m * g0[k].x, r[k].x, fma(m * g0[k].y, r[k].y, ux));
+            uy = fma(m * g1[k].x, r[k].x, fma(m * g1[k].y, r[k].y, uy));
+        }
+    }
+}
+// lane 0 of the row: the x0 / u_prev terms of u0_unc
+__device__ __forceinline__ void mpc_row_add_state(const MpcDeviceConsts& c, double2 xs, double2 up, double& ux, double& uy) {
+    ux += c.Gx[0] * xs.x + c.Gx[1] * xs.y + c.Gu[0] * up.x + c.Gu[1] * up.y;
+    uy += c.Gx[2] * xs.x + c.Gx[3] * xs.y + c.Gu[2] * up.x + c.Gu[3] * up.y;
+}
+
+// The arithmetic of one MPC QP on the 16 lanes of a DPP row from loaded operands: `uxy_in` = this lane's partial sum of
+// u0_unc (the gain-weighted reference stages and, on lane 0, the x0 / u_prev terms), (nc, rax, ray, rb) = row count and
+// this lane's hull row.  All 64 lanes of the wave must call it together (wave-level early out, LDS fences).
+__device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, double ux, double uy,
+                                               int nc, double rax, double ray, double rb, double (*s_hull)[4],
+                                               double& u0x, double& u0y, int& status, unsigned& active, double& margin_out);
+
 // One MPC QP on the 16 lanes of a DPP row (t = lane inside the row).  `rp`: the instance's reference window
 // (stages >= ref_len repeat the last one, MPCSolver.cpp:200-214), `hset`: index of the hull row set, `s_hull`: 8 x 4
 // doubles of LDS owned by this row.  Every lane of the row returns the same u0, status, active mask and margin.
@@ -80,14 +144,25 @@ __device__ __forceinline__ void mpc_row_solve(const MpcDeviceConsts& c, int t, l
         ux += c.Gx[0] * xs.x + c.Gx[1] * xs.y + c.Gu[0] * up.x + c.Gu[1] * up.y;
         uy += c.Gx[2] * xs.x + c.Gx[3] * xs.y + c.Gu[2] * up.x + c.Gu[3] * up.y;
     }
-    // hull rows -> LDS (lanes 0..7 of the instance own one row each)
-    int nc = hull_nc[hset];
-    nc = nc < 0 ? 0 : (nc > WCQP_HULL_ROWS ? WCQP_HULL_ROWS : nc);
-    double rax = 0.0, ray = 0.0, rb = 0.0, rn = 0.0;    // this lane's own hull row (lanes 0..7)
+    // hull rows (lanes 0..7 of the instance own one row each)
+    const int nc = hull_nc[hset];
+    double rax = 0.0, ray = 0.0, rb = 0.0;
     if (t < WCQP_HULL_ROWS) {
         const double2 a = reinterpret_cast<const double2*>(hull_A)[hset * WCQP_HULL_ROWS + t];
         rb = hull_b[hset * WCQP_HULL_ROWS + t];
-        rax = a.x; ray = a.y; rn = sqrt(a.x * a.x + a.y * a.y);
+        rax = a.x; ray = a.y;
+    }
+    mpc_row_finish(c, t, ux, uy, nc, rax, ray, rb, s_hull, u0x, u0y, status, active, margin_out);
+}
+
+__device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, double ux, double uy,
+                                               int nc, double rax, double ray, double rb, double (*s_hull)[4],
+                                               double& u0x, double& u0y, int& status, unsigned& active, double& margin_out)
+{
+    nc = nc < 0 ? 0 : (nc > WCQP_HULL_ROWS ? WCQP_HULL_ROWS : nc);
+    double rn = 0.0;                                     // norm of this lane's own hull row (lanes 0..7)
+    if (t < WCQP_HULL_ROWS) {
+        rn = sqrt(rax * rax + ray * ray);
         s_hull[t][0] = rax; s_hull[t][1] = ray; s_hull[t][2] = rb; s_hull[t][3] = rn;
     }
     // butterfly over the row (DPP, no LDS-pipe round trips): every lane ends with the same sum

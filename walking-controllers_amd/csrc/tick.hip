@@ -70,6 +70,7 @@ struct wcqp_tick_s {
     bool base_elim = false;  // the fused kernel is the base-eliminated one (ik4.hip)
     wcqp_kin_t kin = nullptr;     // use_kinematics: Jacobians, actual poses and hull rows are rebuilt every tick
     KinTick kt{};
+    bool primed = false;          // skewed tick: MPC(ticks_enqueued) has run (the fused launch of tick t carries IK(t) and MPC(t+1))
 };
 
 namespace {
@@ -95,7 +96,7 @@ int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s) {
         const int rck = wcqp::kin_enqueue_tick(h->kin, B, h->kt, d.q_des, h->J_left, h->J_right, h->J_neck, h->J_com, d.state, s);
         if (rck != WCQP_OK) return rck;
     }
-    // base-eliminated IK kernel: MPC, glue, IK and post step in ONE launch
+    // base-eliminated IK kernel: IK + post step of this tick and MPC + glue + plant of the NEXT one in ONE launch (skewed tick)
     if (h->fused && h->base_elim)
         return wcqp_ik::ik4_launch_tick(wcqp::ik_device_params(h->ik), d, h->J_left, h->J_right, h->J_neck, h->J_com,
                                         h->ik_lo, h->ik_up, s);
@@ -165,7 +166,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     int *hn = nullptr, *ph = nullptr;
     rc = WCQP_OK;
 #define A_(ptr, n) if (rc == WCQP_OK) rc = dev_alloc(h, &(ptr), (n))
-    const size_t hsets = params->use_kinematics ? 1 : 3;       // kinematics mode: one live row set per instance, rebuilt on a contact change
+    const size_t hsets = 3;       // rows for {left, right, both} in contact: uploaded, or (kinematics mode) built at upload from the desired foot poses
     A_(ref, B * d.traj_len * 2); A_(hA, B * hsets * 16); A_(hb, B * hsets * 8); A_(hn, B * hsets); A_(ph, B); A_(sw, B * 6);
     A_(d.dcm, B * 2); A_(d.com, B * 2); A_(d.zmp_meas, B * 2); A_(d.u_prev, B * 2); A_(d.u0, B * 2);
     A_(d.c_ref, B * 2); A_(d.v_ref, B * 2); A_(d.v_ref_prev, B * 2); A_(d.p_star, B * 2); A_(d.v_star_prev, B * 2);
@@ -176,17 +177,27 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     A_(d.tick2, 2); A_(d.u0_log, (size_t)d.log_ticks * B * 2); A_(d.dq_log, (size_t)d.log_ticks * B * kDof);
     A_(h->J_left, B * 6 * 29); A_(h->J_right, B * 6 * 29); A_(h->J_neck, B * 3 * 29); A_(h->J_com, B * 3 * 29);
     A_(h->mpc_active, B); A_(h->mpc_margin, B); A_(h->ik_lo, B); A_(h->ik_up, B);
+    // skewed tick (base-eliminated fused kernel): state of the MPC chain, MPC -> IK hand-off, one live hull row set per robot
+    d.skew = (h->fused && h->base_elim) ? 1 : 0;
+    double* jcomp = nullptr;
+    unsigned cm[3] = {0u, 0u, 0u};
+    int cstride = 0, coff_d = 0;
+    const bool compact = d.skew && h->kin && !params->kin_dense_handoff && wcqp::kin_compact_layout(h->kin, cm, &cstride, &coff_d);
+    if (d.skew) {
+        A_(d.mst, B * 16); A_(d.hand, 2 * B * 10); A_(d.live_A, B * 16); A_(d.live_b, B * 8); A_(d.live_nc, B); A_(d.sel_built, B);
+        if (compact) A_(jcomp, B * (size_t)cstride);
+    }
 #undef A_
     if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
     wcqp::mpc_device_consts(h->mpc, &d.mpc);
     d.horizon = N; d.hull_sets = (int)hsets;
+    if (compact) { d.compact = 1; d.jcomp = jcomp; d.cmaskL = cm[0]; d.cmaskR = cm[1]; d.cmaskN = cm[2]; d.cstride = cstride; d.coff_d = coff_d; }
     if (h->kin) {
-        int* sb = nullptr; double* h0 = nullptr;
-        if (dev_alloc(h, &sb, B) != WCQP_OK || dev_alloc(h, &h0, B) != WCQP_OK) { wcqp_tick_destroy(h); return WCQP_E_NOMEM; }
+        double* h0 = nullptr;
+        if (dev_alloc(h, &h0, B) != WCQP_OK) { wcqp_tick_destroy(h); return WCQP_E_NOMEM; }
         d.kin_mode = 1; d.com_h0 = h0;
-        h->kt.tick2 = d.tick2; h->kt.phase0 = ph; h->kt.step_ticks = d.step_ticks; h->kt.sel = d.sel; h->kt.sel_built = sb;
-        h->kt.hull_A = hA; h->kt.hull_b = hb; h->kt.hull_nc = hn;
-        std::memcpy(h->kt.rect, params->foot_rect, sizeof(h->kt.rect));
+        h->kt.tick2 = d.tick2; h->kt.phase0 = ph; h->kt.step_ticks = d.step_ticks;
+        if (compact) { h->kt.jcomp = jcomp; h->kt.cstride = cstride; h->kt.coff_d = coff_d; }
     }
     d.ref_traj = ref; d.hull_tab_A = hA; d.hull_tab_b = hb; d.hull_tab_nc = hn; d.phase0 = ph; d.swing_twist = sw;
     *out = h;
@@ -216,8 +227,23 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
 #define UP_(dst, src, n) WCQP_HIP_TRY(hipMemcpy((void*)(dst), (src), (n), hipMemcpyHostToDevice))
     UP_(d.ref_traj, in->ref_traj, B * d.traj_len * 16);
     UP_(d.phase0, in->phase0, B * 4); UP_(d.swing_twist, in->swing_twist, B * 48);
+    if (d.skew) {
+        // state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (= measured ZMP), p_star, v_star_prev, dcm, spare;
+        // parity-0 hand-off record: the plant state at the start of tick 0 (what a download before the first run reports)
+        std::vector<double> mst(B * 16, 0.0), hand(B * 10, 0.0);
+        for (size_t i = 0; i < B; ++i)
+            for (int ax = 0; ax < 2; ++ax) {
+                double* r = &mst[(i * 2 + ax) * 8];
+                r[0] = in->com0[2 * i + ax]; r[2] = in->com0[2 * i + ax]; r[3] = in->u_init[2 * i + ax];
+                r[4] = in->com0[2 * i + ax]; r[6] = in->dcm0[2 * i + ax];
+                hand[i * 10 + 4 + ax] = in->com0[2 * i + ax]; hand[i * 10 + 6 + ax] = in->dcm0[2 * i + ax];
+            }
+        WCQP_HIP_TRY(hipMemcpy(d.mst, mst.data(), B * 16 * 8, hipMemcpyHostToDevice));
+        WCQP_HIP_TRY(hipMemcpy(d.hand, hand.data(), B * 10 * 8, hipMemcpyHostToDevice));
+        WCQP_HIP_TRY(hipMemset(d.sel_built, 0xff, B * 4));           // -1: every robot builds / copies its live rows at tick 0
+        WCQP_HIP_TRY(hipMemset(d.live_nc, 0, B * 4));
+    }
     if (h->kin) {
-        WCQP_HIP_TRY(hipMemset(h->kt.sel_built, 0xff, B * 4));       // -1: every instance builds its rows at tick 0
         std::vector<double> h0(B);
         for (size_t i = 0; i < B; ++i) h0[i] = in->state0[i * kStateLen + 68];       // desired CoM height = the initial one
         WCQP_HIP_TRY(hipMemcpy((void*)d.com_h0, h0.data(), B * 8, hipMemcpyHostToDevice));
@@ -227,6 +253,14 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
         UP_(h->J_neck, in->J_neck, B * 3 * 29 * 8); UP_(h->J_com, in->J_com, B * 3 * 29 * 8);
     }
     UP_(d.state, in->state0, B * kStateLen * 8); UP_(d.q_des, in->q0, B * kDof * 8);
+    if (h->kin) {
+        // setConvexHullConstraint (...PredictiveController.cpp:364-435) for the three contact pairs, from the DESIRED foot
+        // poses just uploaded (the planned footsteps, WalkingModule.cpp:609-613): the MPC of a tick selects its rows by the pair
+        const int rch = wcqp::hull_tables_from_state((int)B, h->p.foot_rect, d.state, kStateLen, const_cast<double*>(d.hull_tab_A),
+                                                     const_cast<double*>(d.hull_tab_b), const_cast<int*>(d.hull_tab_nc), nullptr);
+        if (rch != WCQP_OK) return rch;
+        WCQP_HIP_TRY(hipDeviceSynchronize());
+    }
     UP_(d.dcm, in->dcm0, B * 16); UP_(d.com, in->com0, B * 16); UP_(d.c_ref, in->com0, B * 16); UP_(d.p_star, in->com0, B * 16);
     UP_(d.zmp_meas, in->u_init, B * 16); UP_(d.u_prev, in->u_init, B * 16);
 #undef UP_
@@ -245,6 +279,7 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     WCQP_HIP_TRY(hipMemset(h->ik_lo, 0, B * 4)); WCQP_HIP_TRY(hipMemset(h->ik_up, 0, B * 4));      // no previous active set at tick 0
     h->uploaded = true;
     h->ticks_enqueued = 0;
+    h->primed = false;
     return WCQP_OK;
 }
 
@@ -253,6 +288,12 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
     // the trajectories hold max_ticks + N + 1 stages per instance: a tick beyond that would read its neighbour's
     if ((long)h->ticks_enqueued + n_ticks > (long)h->p.max_ticks) return WCQP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    if (h->d.skew && !h->primed && n_ticks > 0) {
+        // the fused launch of tick t carries IK(t) and MPC(t+1): MPC(0) goes first, on its own
+        const int rc = wcqp_ik::ik4_launch_tick_prime(h->d, h->ticks_enqueued, s);
+        if (rc != WCQP_OK) return rc;
+        h->primed = true;
+    }
     // kGraphTicks ticks per graph (the tick index lives in HBM, so the graph is tick-invariant): one
     // hipGraphLaunch costs about as much as four plain launches.  The graph is captured with phases 0, 1, 0, ...
     // and therefore replayed only from an even tick index; an odd one takes a plain tick first.
@@ -293,7 +334,22 @@ int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
     WCQP_HIP_TRY(hipDeviceSynchronize());
 #define DN_(dst, src, n) if (dst) WCQP_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
     DN_(out->u0_log, d.u0_log, (size_t)d.log_ticks * B * 16); DN_(out->dq_log, d.dq_log, (size_t)d.log_ticks * B * kDof * 8);
-    DN_(out->q_des, d.q_des, B * kDof * 8); DN_(out->dcm, d.dcm, B * 16); DN_(out->com, d.com, B * 16);
+    DN_(out->q_des, d.q_des, B * kDof * 8);
+    if (d.skew) {
+        // the MPC chain is one tick ahead of the IK; the plant state at the start of tick n (= after n ticks) is what MPC(n)
+        // put into its hand-off record (parity n & 1) before it advanced the plant
+        if (out->dcm || out->com) {
+            std::vector<double> hand(B * 10);
+            WCQP_HIP_TRY(hipMemcpy(hand.data(), d.hand + (size_t)(h->ticks_enqueued & 1) * B * 10, B * 10 * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < B; ++i)
+                for (int ax = 0; ax < 2; ++ax) {
+                    if (out->com) out->com[2 * i + ax] = hand[i * 10 + 4 + ax];
+                    if (out->dcm) out->dcm[2 * i + ax] = hand[i * 10 + 6 + ax];
+                }
+        }
+    } else {
+        DN_(out->dcm, d.dcm, B * 16); DN_(out->com, d.com, B * 16);
+    }
     DN_(out->mpc_fail, d.mpc_fail, B * 8); DN_(out->ik_fail, d.ik_fail, B * 8);
     DN_(out->hot_try, d.hot_try, B * 8); DN_(out->hot_hit, d.hot_hit, B * 8); DN_(out->tick, d.tick2 + (h->ticks_enqueued & 1), 4);
 #undef DN_

@@ -8,6 +8,7 @@
 #pragma once
 #include "wcqp_internal.h"
 #include "mpc_device.h"
+#include "hull_device.h"
 
 namespace wcqp_tick {
 
@@ -43,22 +44,50 @@ struct TickDev {
     // tick's active bounds (the kernel's own active_lower / active_upper words, 8 B per robot) are tried first
     int hot_start;
     long long *hot_try, *hot_hit;     // [B] ticks on which a previous active set was tried / accepted
+    // ---- the SKEWED tick of the base-eliminated fused kernel (ik4.hip): the launch of tick t carries IK(t) and MPC(t+1).
+    // The MPC chain MPC(t) -> ZMP-CoM law -> LIPM plant -> MPC(t+1) does not depend on the IK, so the MPC of the NEXT tick
+    // runs in the shadow of this tick's Jacobian loads; its outputs reach IK(t+1) through a hand-off record.
+    int skew;
+    double* mst;        // [B][2][8] state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (= measured ZMP), p_star,
+                        //           v_star_prev, dcm, spare - one 64-byte record per axis, loaded as four 16-byte pieces
+    double* hand;       // [2][B][10] MPC(t) -> IK(t) at parity t & 1: p_star xy, v_star xy, com(t) xy, dcm(t) xy, mpc_ok, spare
+                        //           (com(t) / dcm(t): the plant state at the START of tick t - what wcqp_tick_download reports)
+    double* live_A; double* live_b; int* live_nc; int* sel_built;     // one live hull row set per robot ([B][8][2], [B][8], [B])
+                        //           and the contact pair it holds: copied from the robot's three-set table on a contact change, so
+                        //           that the rows of a tick are loaded from a fixed address, without waiting for the contact pair
+    // ---- compact kinematics -> IK hand-off (tick-internal): per robot one record per joint, [C lin3 | X] with X = the
+    // joint's column of the ONE frame Jacobian it is on the path of (left foot 6, right foot 6, neck angular 3), and the
+    // three vectors p_frame - p_base that make up the base blocks.  cmask*: joints on the path of the left sole / right sole / neck.
+    int compact;
+    const double* jcomp; unsigned cmaskL, cmaskR, cmaskN; int cstride, coff_d;
 };
+
+// offset (doubles) of joint c's record inside a robot's compact Jacobian block, and the frame the joint belongs to
+// (0 none, 1 left sole, 2 right sole, 3 neck): records are 4 (CoM column only), 6 (+ neck angular) or 10 (+ a foot's 6) long
+__host__ __device__ inline int compact_offset(unsigned mL, unsigned mR, unsigned mN, int c, int& kind) {
+    const unsigned below = (1u << c) - 1u;
+    kind = ((mL >> c) & 1u) ? 1 : (((mR >> c) & 1u) ? 2 : (((mN >> c) & 1u) ? 3 : 0));
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 4 * c + 6 * __popc((mL | mR) & below) + 2 * __popc(mN & below);
+#else
+    return 4 * c + 6 * __builtin_popcount((mL | mR) & below) + 2 * __builtin_popcount(mN & below);
+#endif
+}
 
 // Per-tick kinematics (wcqp_tick_params::use_kinematics): what the kinematics kernel needs beyond the model when it
 // runs inside the tick.  The joints are the integrated q_des; the floating base is ANCHORED at the stance foot of the
 // current step, the way the reference does it (WalkingFK::evaluateWorldToBaseTransformation with the fixed foot,
 // WM/src/WalkingForwardKinematics.cpp:160-256, called at WM/src/WalkingModule.cpp:560-576): world_T_base =
 // world_T_sole,desired * (base_T_sole(q))^-1, so the stance sole sits exactly on its planned pose and the base moves
-// as the stance leg's joints do.  The support-polygon rows are rebuilt from the DESIRED foot poses whenever the
-// contact pair changes (WalkingController::setConvexHullConstraint, ...PredictiveController.cpp:364-435).
+// as the stance leg's joints do.  (The support-polygon rows of the three contact pairs are built from the DESIRED foot
+// poses when those are uploaded - hull.hip - and selected per tick by the MPC: WalkingController::setConvexHullConstraint,
+// ...PredictiveController.cpp:364-435, switches rows only when the pair changes.)
 struct KinTick {
     const int* tick2; int phase;      // tick index (TickDev::tick2)
     const int* phase0; int step_ticks;   // anchor foot = stance foot of the step: ((t + phase0) % (2 step_ticks)) / step_ticks
-    const int* sel;           // [B] contact pair of this tick (0 left, 1 right, 2 both)
-    int* sel_built;           // [B] contact pair the current hull rows were built for (-1: none yet)
-    double* hull_A; double* hull_b; int* hull_nc;     // [B][8][2], [B][8], [B]
-    double rect[8];           // foot rectangle corners (x, y) x 4 in the foot frame
+    // compact hand-off (TickDev::jcomp): the kernel writes the per-joint records instead of the four dense Jacobians
+    double* jcomp; int cstride, coff_d;
+    double* dbg;              // diagnostic builds (-DWCQP_KIN_STAMPS): where the phase stamps go
 };
 
 }  // namespace wcqp_tick
@@ -159,6 +188,104 @@ __device__ __forceinline__ void tick_post_joint(const TickDev& d, int i, int t, 
 __device__ __forceinline__ void tick_post_instance(const TickDev& d, int i, int t, bool ik_ok) {
     if (!ik_ok || tick_robot_stopped(d, i)) d.ik_fail[i] += 1;
     d.sel[i] = contact_code(t + 1, d.phase0[i], d.step_ticks, d.ds_ticks);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Skewed tick: the MPC chain of tick t on the 16 lanes of a DPP row (j = lane in the row; lanes 0 / 1 also own one
+// horizontal axis each).  tick_mpc_issue puts every load of the chain in flight; tick_mpc_finish does the arithmetic:
+// contact pair -> (on a change) hull rows, condensed MPC, LIPM reference, ZMP-CoM law, synthetic plant, hand-off record.
+struct TickMpcRegs {
+    wcqp_mpc::MpcLoads L;
+    double2 s01, s23, s45, s67;     // lanes 0 / 1: this axis' state record (TickDev::mst)
+    double2 ha; double hb; int nc;  // live hull row of lane j < 8, row count
+    int phase0, built;
+};
+__device__ __forceinline__ void tick_mpc_issue(const TickDev& d, int j, long inst, int t, TickMpcRegs& R) {
+    const double2* rp = reinterpret_cast<const double2*>(d.ref_traj) + inst * d.traj_len + t;
+    R.phase0 = d.phase0[inst];
+    R.built = d.sel_built[inst];
+    const double2* sp = reinterpret_cast<const double2*>(d.mst + (inst * 2 + (j & 1)) * 8);
+    R.s01 = sp[0]; R.s23 = sp[1]; R.s45 = sp[2]; R.s67 = sp[3];
+    wcqp_mpc::mpc_window_loads(d.mpc, j, rp, d.horizon + 1, R.L);
+    R.nc = d.live_nc[inst];
+    const int jr = j & 7;
+    R.ha = reinterpret_cast<const double2*>(d.live_A)[inst * WCQP_HULL_ROWS + jr];
+    R.hb = d.live_b[inst * WCQP_HULL_ROWS + jr];
+}
+__device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double (*s_hull)[4]) {
+    // contact pair of tick t; the live row set follows it (WalkingController::setConvexHullConstraint switches rows only
+    // when the pair changes, ...PredictiveController.cpp:369-374)
+    const int code = contact_code(t, R.phase0, d.step_ticks, d.ds_ticks);
+    const bool stale = code != R.built;
+    if (__ballot(stale) != 0ull) {
+        if (stale && live) {
+            double* lA = d.live_A + inst * (2 * WCQP_HULL_ROWS);
+            double* lb = d.live_b + inst * WCQP_HULL_ROWS;
+            const long hset = inst * 3 + code;
+            if (j < WCQP_HULL_ROWS) {
+                reinterpret_cast<double2*>(lA)[j] = reinterpret_cast<const double2*>(d.hull_tab_A)[hset * WCQP_HULL_ROWS + j];
+                lb[j] = d.hull_tab_b[hset * WCQP_HULL_ROWS + j];
+            }
+            if (j == 0) { d.live_nc[inst] = d.hull_tab_nc[hset]; d.sel_built[inst] = code; }
+        }
+        // the rows were written by other lanes of this wave: make them visible, then read them back
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        R.nc = d.live_nc[inst];
+        const int jr = j & 7;
+        R.ha = reinterpret_cast<const double2*>(d.live_A)[inst * WCQP_HULL_ROWS + jr];
+        R.hb = d.live_b[inst * WCQP_HULL_ROWS + jr];
+    }
+    // ---- the condensed MPC (mpc_device.h): x0 = measured DCM, u_prev = previous output (MPCSolver.cpp:244-245)
+    double ux, uy;
+    wcqp_mpc::mpc_row_partial(d.mpc, j, R.L, ux, uy);
+    if (d.horizon >= 4 * wcqp_mpc::kLanesPerInstance)
+        wcqp_mpc::mpc_row_extra_passes(d.mpc, j, reinterpret_cast<const double2*>(d.ref_traj) + inst * d.traj_len + t, d.horizon + 1, ux, uy);
+    {
+        // lane 0 holds the x axis' record, lane 1 the y axis': the y entries come over by DPP (row_shl:1)
+        const double dcm_y = wcqp_mpc::row_move<0x101>(R.s67.x), up_y = wcqp_mpc::row_move<0x101>(R.s23.y);
+        if (j == 0) wcqp_mpc::mpc_row_add_state(d.mpc, make_double2(R.s67.x, dcm_y), make_double2(R.s23.y, up_y), ux, uy);
+    }
+    double u0x, u0y, margin;
+    int st;
+    unsigned act;
+    wcqp_mpc::mpc_row_finish(d.mpc, j, ux, uy, R.nc, j < WCQP_HULL_ROWS ? R.ha.x : 0.0, j < WCQP_HULL_ROWS ? R.ha.y : 0.0,
+                             j < WCQP_HULL_ROWS ? R.hb : 0.0, s_hull, u0x, u0y, st, act, margin);
+    const bool mpc_ok = st == WCQP_STATUS_SOLVED || st == WCQP_STATUS_OUTSIDE_HULL;
+    const double r_y = wcqp_mpc::row_move<0x111>(R.L.r[0].y);          // lane 1 <- lane 0 (row_shr:1)
+    if (j < 2 && live) {
+        const int ax = j;
+        const double c_ref0 = R.s01.x, v_ref_prev = R.s01.y, com = R.s23.x, u_prev = R.s23.y;
+        const double p_star0 = R.s45.x, v_star_prev = R.s45.y, xi = R.s67.x;
+        // StableDCMModel::integrateModel (StableDCMModel.cpp:63-90), Tustin integrator
+        const double rr = ax == 0 ? R.L.r[0].x : r_y;        // reference DCM of tick t: stage 0 of the window (lane 0 holds it)
+        const double vr = -d.omega * (c_ref0 - rr);
+        const double c_ref = c_ref0 + 0.5 * d.dT * (vr + v_ref_prev);
+        const double u = mpc_ok ? (ax == 0 ? u0x : u0y) : u_prev;        // hold the last command on failure
+        // WalkingZMPController::evaluateControl (WalkingZMPController.cpp:146-173); the measured ZMP is the previous command
+        const double v = d.k_com * (c_ref - com) - d.k_zmp * (u - u_prev) + vr;
+        const double p_star = p_star0 + 0.5 * d.dT * (v + v_star_prev);
+        // synthetic plant: LIPM with a bounded disturbance
+        const double com1 = com + d.dT * (-d.omega * (com - xi));
+        const double xi1 = d.a * xi + d.b * u + d.noise * disturbance(d.seed, (unsigned long long)(d.first + inst), t, ax);
+        double2* sp = reinterpret_cast<double2*>(d.mst + (inst * 2 + ax) * 8);
+        sp[0] = make_double2(c_ref, vr); sp[1] = make_double2(com1, u); sp[2] = make_double2(p_star, v); sp[3] = make_double2(xi1, 0.0);
+        // hand-off to the IK of tick t (desired CoM position / velocity, WalkingModule.cpp:686-695) + the plant state at the start of tick t
+        double* hd = d.hand + ((size_t)(t & 1) * d.batch + inst) * 10;
+        hd[ax] = p_star; hd[2 + ax] = v; hd[4 + ax] = com; hd[6 + ax] = xi;
+        if (ax == 0) hd[8] = mpc_ok ? 1.0 : 0.0;
+        if (t < d.log_ticks) d.u0_log[((size_t)t * d.batch + inst) * 2 + ax] = u;
+    }
+}
+// swing_profile with the instance's phase offset already in a register
+__device__ __forceinline__ double swing_profile_at(const TickDev& d, int phase0, int t) {
+    if (!d.kin_mode) return 1.0;
+    const int sidx = ((t + phase0) % (2 * d.step_ticks)) % d.step_ticks;
+    const int ss = d.step_ticks - d.ds_ticks;
+    if (sidx < d.ds_ticks || ss < 1) return 0.0;
+    const double x = (double)(sidx - d.ds_ticks) / (double)ss;
+    return 10.392304845413264 * x * (1.0 - x) * (1.0 - 2.0 * x);
 }
 #endif
 

@@ -45,6 +45,10 @@ int qp_pair_enqueue(wcqp_mpc_t mpc, wcqp_ik_t ik, int batch, const wcqp_qp_step&
 bool ik_fast_ok(wcqp_ik_t h);                  // the handle qualifies for the base-eliminated kernel (ik4.hip)
 void mpc_dynamics(wcqp_mpc_t h, double* a, double* b);
 int kin_prepare(wcqp_kin_t h);
+// hull.hip: the three support-polygon row sets (left, right, both feet in contact) of every robot from the desired foot poses of its pose block
+int hull_tables_from_state(int batch, const double* foot_rect_host, const double* state_dev, int state_len,
+                           double* tab_A, double* tab_b, int* tab_nc, hipStream_t stream);
+bool kin_compact_layout(wcqp_kin_t h, unsigned masks[3], int* stride, int* off_d);   // kin.hip: layout of the tick's compact Jacobian hand-off
 
 // ---- wave-level helpers used by the kernels (gfx950, wave64) -------------------------
 #if defined(__HIPCC__)

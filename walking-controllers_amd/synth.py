@@ -43,12 +43,28 @@ ICUB_JOINT_REG_DEG = np.array([15, 0, 0,
 # Posture the WALK scenario (synth_walk_batch, per-tick kinematics) starts from and regularises to.  The shipped
 # jointRegularization (ICUB_JOINT_REG_DEG) belongs to the real iCub URDF, which is not in the repository: on the
 # iCub-SHAPED tree of icub_like_model() it puts the soles 15 cm ahead of the centre of mass and tilts them by 65 degrees,
-# a robot no LIPM can balance.  This is the tree's own crouch: thighs 35 deg forward, knees 70 deg (room to stretch a leg while the pelvis sways over the other foot), soles flat under the CoM.
+# a robot no LIPM can balance.  This is the tree's own crouch: thighs 50 deg forward, knees 100 deg, soles flat under the
+# CoM.  The depth is what keeps every leg away from its straight (singular) configuration while the pelvis sways over the
+# other foot: tools/walk_diag.py, 65536 robots x 1024 ticks - the straightest knee stays above 31 deg and no IK becomes
+# infeasible (at 35 / 70 deg 5.8 % of the robots over-stretched a leg at some point and their IK had no solution).
 WALK_POSTURE_DEG = np.array([5, 0, 0,
                              -7, 22, 11, 30,
                              -7, 22, 11, 30,
-                             -35.0, 0.406, -0.131, 70.0, -35.0, -0.351,
-                             -35.0, 0.406, -0.131, 70.0, -35.0, -0.351], float)
+                             -50.0, 0.406, -0.131, 100.0, -50.0, -0.351,
+                             -50.0, 0.406, -0.131, 100.0, -50.0, -0.351], float)
+# Joint velocity limits of the walk scenario [rad/s] (the reference reads them from the robot at run time,
+# RobotHelper.cpp:288-298; there is no value in the repository): legs 1.5, torso and arms 0.3.  The twelve leg joints are
+# all but determined by the 15 task rows, so a leg joint on its limit soon leaves the QP without a solution, while the
+# upper body is where the QP has freedom: with these limits a bound is active on ~12 % of the robot-ticks (the upper
+# body's, mostly while the pelvis changes sides) and none of 65536 robots fails in 1024 ticks.
+WALK_VMAX = np.array([0.3] * 11 + [1.5] * 12, float)
+# Swing foot of the walk scenario: LIFTED - the vertical twist amplitude is positive (the zero-net-displacement profile of
+# tick_device.h: up in the first half of the single support, down in the second; 0.04-0.08 m/s peak = 0.9-1.8 cm of lift),
+# small horizontal / angular scatter.  (An isotropic random twist pushes the foot down and outwards as often as up: that
+# stretches the leg.)
+WALK_SWING_LIFT = (0.04, 0.08)
+WALK_SWING_LIN_SIGMA = 0.01
+WALK_SWING_ANG_SIGMA = 0.02
 
 _M1 = np.uint64(0x9E3779B97F4A7C15)
 _M2 = np.uint64(0xBF58476D1CE4E5B9)
@@ -404,7 +420,7 @@ def synth_kin_batch(count: int, seed: int = 31415, first: int = 0, joint_sigma: 
 
 def synth_walk_kin_batch(count: int, first: int = 0) -> dict:
     """Base poses / joint angles the walk scenario starts from: robots standing upright on the tree's own crouch
-    (WALK_POSTURE_DEG), a degree of scatter (a stance wider than ~14 cm over-stretches the far leg when the pelvis sways over one foot)."""
+    (WALK_POSTURE_DEG), a degree of scatter."""
     return synth_kin_batch(count, seed=27182, first=first, joint_sigma=0.015, posture_deg=WALK_POSTURE_DEG, base_rot_sigma=0.015)
 
 
@@ -425,7 +441,8 @@ def synth_walk_batch(count: int, n_ticks: int, poses: np.ndarray, kin_batch: dic
     u_ph = rng.uniform(2)
     phase0 = ((u_ph[:, 0] < 0.5) * step_ticks + (0.35 + 0.2 * u_ph[:, 1]) * ds_ticks).astype(np.int32)
     dcm_n = rng.normal(2, 0.002)
-    swing = rng.normal(6, 0.05)        # amplitude of the swing foot's twist profile (zero net displacement: tick_device.h)
+    # amplitudes of the swing foot's twist profile (zero net displacement: tick_device.h): the foot is lifted
+    swing = np.concatenate([rng.normal(2, WALK_SWING_LIN_SIGMA), rng.uniform(1, *WALK_SWING_LIFT), rng.normal(3, WALK_SWING_ANG_SIGMA)], axis=1)
     neck_w = rng.normal(3, 0.02)
     state0 = np.array(poses, dtype=np.float64, copy=True)
     for src, dst, k in (("p_left", "pd_left", 3), ("R_left", "Rd_left", 9), ("p_right", "pd_right", 3), ("R_right", "Rd_right", 9)):
