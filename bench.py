@@ -9,6 +9,7 @@ instances per GPU (default 4096, the batch both configs are quoted on), every
 instance cold-started.  Inputs are resident in HBM before the timed region starts.
 
     python bench.py                       # 1 GPU
+    python bench.py --gpus N              # starts N ranks itself (one per GPU; refuses when fewer GPUs are visible)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -26,10 +27,11 @@ Instances are independent, so ranks shard the batch with no data-path collective
 rank 0 and gather of solutions to every step and reports that rate too.
 
 The JSON line carries
-  roofline      HBM roofline of the dominant kernel (the IK kernel): algorithmic bytes per
-                launch (5240 B/IK-QP x batch) / its average launch duration,
-                measured with HIP events on the launch stream in a pass of its own after the timed steps
-                (back-to-back launches of that kernel alone, cold and resident inputs);
+  roofline      HBM roofline of the dominant kernel - the one-launch step `qp_pair_kernel` (IK and MPC workgroups in one grid):
+                algorithmic bytes per launch (6296 B per robot-tick = 5240 B/IK-QP + 1056 B/MPC-QP, SURVEY.md §8d, x batch) / its
+                average launch duration, measured with HIP events on the launch stream in a pass of its own after the timed
+                steps (back-to-back launches of that kernel alone, cold and resident inputs); `kernels` keeps the IK and
+                the MPC kernel alone;
   cpu_baseline  oracle/wc_oracle.c (OSQP-algorithm restatement for the MPC, dense dual
                 active set for the IK) timed on this box's host cores on a bounded sample.
 """
@@ -81,32 +83,44 @@ def main():
                     "(round-1 form) instead of per-tick kinematics")
     ap.add_argument("--tick-dense-handoff", action="store_true", help="tick workload with kinematics: four dense Jacobians between the kinematics and the "
                     "solve kernel instead of the compact per-joint records (A/B; same results)")
+    ap.add_argument("--ticks-per-launch", type=int, default=0, help="tick workload without per-tick kinematics: ticks the fused kernel runs per launch (0 = the library's default, 1 = one launch per tick)")
     ap.add_argument("--tick-cold-ik", action="store_true", help="tick workload: no IK hot start (every tick walks the active set from the unconstrained optimum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     args = ap.parse_args()
 
+    # `--gpus N` without a launcher: this process becomes the launcher - N children, one rank per GPU, started BEFORE
+    # anything here touches the GPU (the parent never does); rank 0's JSON line is relayed, any child's failure is ours
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
+
     import torch
     import walking_controllers_amd as wca
 
+    launched = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node == --gpus, "
+                         "or without a launcher: bench.py then starts the ranks itself)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the solve path has no CPU fallback")
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(1, ndev)          # == local_rank on a full node; lets a 1-GPU box rehearse N > 1
+    backend = os.environ.get("WCQP_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for rehearsals on fewer GPUs
+    if ndev < world and backend != "gloo":
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s): one rank per GPU (WCQP_DIST_BACKEND=gloo lets a smaller box "
+                         "REHEARSE the launch with the ranks sharing its GPUs - not a measurement)" % (world, ndev))
+    dev_index = local_rank % max(1, ndev)          # == local_rank on a full node
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    backend = os.environ.get("WCQP_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
-    if world > 1:
+    if launched:                                   # under a launcher, also with ONE rank (RCCL with world size 1 is a valid group)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     B = args.batch
     first = rank * B
@@ -134,7 +148,7 @@ def main():
     set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
     K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
-    P = args.pipelines if args.pipelines > 0 else (1 if (args.exchange and world > 1) else 3)
+    P = args.pipelines if args.pipelines > 0 else (1 if (args.exchange and dist is not None) else 3)
 
     def outputs():
         return dict(u0=torch.zeros(B, 2, dtype=torch.float64, device=dev), mstat=torch.zeros(B, dtype=torch.int32, device=dev),
@@ -153,7 +167,7 @@ def main():
     sp = stream.cuda_stream
     # one stream per pipeline: wcqp_qp_enqueue_steps then makes the two calls of a step as ONE launch (IK and MPC workgroups
     # side by side); --streams 2 keeps them as two launches on two streams (the exchange path always does)
-    n_streams = args.streams if args.streams else (2 if (args.exchange and world > 1 and B <= 32768) else 1)
+    n_streams = args.streams if args.streams else (2 if (args.exchange and dist is not None and B <= 32768) else 1)
     two_streams = n_streams == 2
     stream_mpc = torch.cuda.Stream(dev) if two_streams else stream
     sp_mpc = stream_mpc.cuda_stream
@@ -187,7 +201,7 @@ def main():
 
     # optional RCCL exchange (rank 0 owns the whole batch)
     exch = None
-    if args.exchange and world > 1:
+    if args.exchange and dist is not None:
         in_keys = ("x0", "ref", "u_prev", "hull_A", "hull_b", "J_left", "J_right", "J_neck", "J_com", "q", "state")
         d0 = sets[0]
         if rank == 0:
@@ -293,6 +307,39 @@ def main():
     ik_iters = float(outs[0]["iit"].double().mean().item())
     frac_active = float(((outs[0]["ilo"] | outs[0]["iup"]) != 0).double().mean().item())
 
+    # what was timed is what the committed golden vectors hold (tests/golden/: the exact fp64 optimum of the same seeded
+    # instances): every pipeline's LAST batch of the timed region against them.  Input set k is the batch rolled by k B / K
+    # rows, so output row r of a step that read set k belongs to instance (r - k B / K) mod B.
+    golden = {"golden_max_abs_err": None, "golden_active_set_mismatches": None}
+    if first == 0 and NH == 50 and args.ik_form == "qpoases" and abs(args.ik_vmax - 0.5) < 1e-12 and not exch:
+        try:
+            gm = np.load(os.path.join(ROOT, "tests", "golden", "mpc_cfg2_b4096.npz"), allow_pickle=False)
+            gi = np.load(os.path.join(ROOT, "tests", "golden", "ik_qpoases_v050_b1024.npz"), allow_pickle=False)
+            err, mism, rows_checked = 0.0, 0, 0
+            last = args.warmup + args.steps - 1
+            for p_ in range(P):
+                i_last = last - ((last - p_) % P)
+                if i_last < args.warmup:
+                    continue
+                inst = (np.arange(B) - (i_last % K) * max(1, B // K)) % B
+                o = {k: v.cpu().numpy() for k, v in outs[p_].items()}
+                m = inst < int(gm["count"])
+                err = max(err, float(np.abs(o["u0"][m] - gm["u0"][inst[m]]).max()))
+                sure = (gm["mu_min_active"][inst[m]] > 1e-7) & (gm["slack_min_inactive"][inst[m]] > 1e-7)
+                mism += int((o["mact"][m].astype(np.uint32)[sure] != gm["active"][inst[m]][sure]).sum())
+                mism += int((o["mstat"][m] != 0).sum())
+                n = inst < int(gi["count"])
+                err = max(err, float(np.abs(o["dq"][n] - gi["dq"][inst[n]]).max()))
+                sure = (gi["mu_min_active"][inst[n]] > 1e-7) & (gi["slack_min_inactive"][inst[n]] > 1e-7) & (gi["status"][inst[n]] == 0)
+                mism += int(((o["ilo"][n].astype(np.uint32) != gi["active_lower"][inst[n]]) | (o["iup"][n].astype(np.uint32) != gi["active_upper"][inst[n]]))[sure].sum())
+                mism += int((o["istat"][n] != gi["status"][inst[n]]).sum())
+                rows_checked += int(m.sum()) + int(n.sum())
+            golden = {"golden_max_abs_err": err, "golden_active_set_mismatches": mism, "golden_rows_checked": rows_checked,
+                      "golden": "every pipeline's last timed batch vs tests/golden/mpc_cfg2_b4096.npz (u0, active rows, status) and "
+                                "ik_qpoases_v050_b1024.npz (dq, active bounds, status); active sets where the strict-complementarity margin exceeds 1e-7"}
+        except Exception as e:                      # a bench line without the check is still a bench line; say why
+            golden["golden_error"] = repr(e)
+
     # ---- kernel durations, measured AFTER the timed region in short passes of their own: HIP events on the launch
     # stream around n back-to-back launches of one kernel (a pair of event records costs about as much as a launch, so
     # nothing is bracketed singly); `cold` rotates over the K input sets like the timed region, `resident` re-reads one
@@ -390,8 +437,8 @@ def main():
             "mpc_ms": mpc_ms, "mpc_ms_resident_inputs": mpc_ms_res, "mpc_qps_per_gpu": B / (mpc_ms * 1e-3),
             "mpc_hbm_frac": mpc_bytes * B / (mpc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mpc_bytes_per_qp": mpc_bytes,
         },
-        "solved": {"ik": n_ok_ik, "mpc": n_ok_mpc, "of": B, "ik_mean_active_set_changes": ik_iters,
-                   "ik_frac_with_active_bounds": frac_active},
+        "solved": dict({"ik": n_ok_ik, "mpc": n_ok_mpc, "of": B, "ik_mean_active_set_changes": ik_iters,
+                        "ik_frac_with_active_bounds": frac_active}, **golden),
     }
     # HBM bytes per launch from the PMC passes of tools/pmc/collect.sh (committed summary)
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
@@ -409,6 +456,25 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* per child, rendezvous on
+    127.0.0.1), relay rank 0's JSON line, exit non-zero when any rank does.  The parent makes no GPU call at all."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
 
 def max_over_ranks(dist, torch, dev, value):
@@ -511,7 +577,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
             data = wca.synth.synth_tick_batch(cnt, T, first=f0)
             iks = wca.IkSolver(form=ik_form, v_max=vmax)
         pp = wca.TickPipeline(cnt, T, wca.MpcSolver(horizon=50), iks, first=f0, kin=kin, ik_hot_start=not args.tick_cold_ik,
-                              kin_dense_handoff=args.tick_dense_handoff)
+                              kin_dense_handoff=args.tick_dense_handoff, ticks_per_launch=args.ticks_per_launch)
         pp.upload(data)
         pipes.append(pp)
     stream = torch.cuda.current_stream(dev)
@@ -633,12 +699,18 @@ def cpu_baseline(mb, ib, args):
     warm_ticks = 40
     nw = min(n, 2048)
     wb = wca_synth_mpc(nw, 50 + warm_ticks)
+    # wall time, like the cold numbers: the same call with 8 and with `warm_ticks` warm ticks - the difference is 32 warm
+    # ticks of every robot without the cold solve and the set-up in front of them
+    t = time.perf_counter(); co.mpc_batch_osqp_warm(mp, wb, 8, nthreads=cores); wall_8 = time.perf_counter() - t
+    t = time.perf_counter()
     _, warm_iters, warm_thread_s, warm_fail = co.mpc_batch_osqp_warm(mp, wb, warm_ticks, nthreads=cores)
-    mpc_warm_qps = nw * warm_ticks / (warm_thread_s / cores) if warm_thread_s > 0 else None
+    wall_w = time.perf_counter() - t
+    mpc_warm_qps = nw * (warm_ticks - 8) / (wall_w - wall_8) if wall_w > wall_8 else None
     return {"value": 2 * n * reps / (wall_m + wall_i), "unit": "QP/s", "cores": cores, "kind": "port",
             "mpc_warm_qps": mpc_warm_qps, "mpc_warm_mean_iters": warm_iters, "mpc_warm_nonconverged": warm_fail,
-            "mpc_warm_sample": "%d robots x %d warm ticks each after one cold solve (set-up not timed): persistent workspace, "
-                               "bounds + gradient update, warm-started OSQP-restatement solve" % (nw, warm_ticks),
+            "mpc_warm_sample": "%d robots x %d warm ticks each after one cold solve: persistent workspace, bounds + gradient update, "
+                               "warm-started OSQP-restatement solve; WALL time of the call with %d warm ticks minus the one with 8 "
+                               "(set-up and cold solve cancel)" % (nw, warm_ticks, warm_ticks),
             "sample": "%d x the first %d instances of the same workload (1 MPC via OSQP-restatement + 1 IK via %s per instance), "
                       "OpenMP static split" % (reps, n, "dense active set" if args.ik_form == "qpoases" else "OSQP-restatement"),
             "mpc_qps": n * reps / wall_m, "mpc_qps_is": "cold start: a new OSQP workspace per QP", "ik_qps": n * reps / wall_i,

@@ -21,9 +21,15 @@
  *     allocation, no sync inside).  `*_host` entry points take HOST pointers,
  *     stage through the handle's own device buffers and synchronise.
  *   - the handle owns every buffer it allocates; the caller owns inputs/outputs;
- *     no pointer is retained past a call.  A handle is single-caller (like the
- *     reference's solvers, which are only touched under WalkingModule's m_mutex,
- *     WM/src/WalkingModule.cpp:429).
+ *     no pointer is retained past a call.  On the HOST side a handle is single-caller
+ *     (like the reference's solvers, which are only touched under WalkingModule's m_mutex,
+ *     WM/src/WalkingModule.cpp:429): one thread at a time calls into it.  On the DEVICE
+ *     side the work a `*_device` call (or wcqp_qp_enqueue_steps) enqueues only READS the
+ *     handle's device state (constants uploaded at create / wcqp_ik_set_posture), so solves
+ *     of one wcqp_mpc_t / wcqp_ik_t pair enqueued on several streams may run concurrently -
+ *     the caller keeps their input / output arrays apart.  (wcqp_ik_set_posture and the
+ *     `*_host` entry points synchronise the device first; a wcqp_tick_t owns its state and
+ *     takes one stream at a time.)
  */
 #ifndef WCQP_H
 #define WCQP_H
@@ -62,6 +68,12 @@ const char* wcqp_strerror(int code);
 int wcqp_version(void);
 /* number of visible HIP devices (0 on a CPU-only host; never initialises a context) */
 int wcqp_device_count(void);
+/* HIP streams for hosts that reach this library through an FFI and have no HIP binding of their own (ctypes, cgo, JNI):
+ * what the `stream` argument of the `*_device` entry points takes.  Non-blocking streams of the current device;
+ * wcqp_stream_synchronize(NULL) waits for the whole device.  (The reference has no counterpart: its solvers are synchronous.) */
+int wcqp_stream_create(void** out);
+int wcqp_stream_destroy(void* stream);
+int wcqp_stream_synchronize(void* stream);
 
 /* =====================================================================================
  * DCM-MPC  — replaces  WalkingController::{initialize, setConvexHullConstraint,
@@ -158,8 +170,9 @@ int wcqp_hull_from_feet_host(int32_t batch, const double* foot_rect,
                                           instance: ~5 % faster than 2 in interleaved A/B runs;
                                           needs use_com_as_constraint (one 16x16 tile), else runs as 2        */
 #define WCQP_IK_ALG_NULLSPACE_16L 4    /* null-space kernel on 16 lanes per instance, 4 instances per wave
-                                          (csrc/ik3.hip): 1.6x the throughput of 3 on a full chip, ahead at every batch
-                                          size (the default); needs use_com_as_constraint, else runs as 2       */
+                                          (csrc/ik3.hip): 1.6x the throughput of 3 on a full chip; the fall-back of
+                                          algorithm 5 for Jacobians without the MIXED pattern and the kernel of
+                                          WCQP_IK_JAC_GENERAL; needs use_com_as_constraint, else runs as 2          */
 #define WCQP_IK_ALG_BASE_ELIM 5        /* base unknowns eliminated in closed form through the left-foot rows, 23-variable
                                           QP in range space (csrc/ik4.hip): what the default resolves to when the CoM is a
                                           constraint, every joint weight is > 0 and the neck weight is positive definite;
@@ -371,6 +384,12 @@ typedef struct wcqp_tick_params {
      * instead of the 4.4 KB of four dense Jacobians, ~70 % of which are structural zeros.  1 = dense Jacobians (the layouts
      * of wcqp_kin_jacobians_* / wcqp_ik_solve_*); same results. */
     int32_t kin_dense_handoff;
+    /* Ticks per launch of the fused kernel (default IK kernel, no per-tick kinematics): the robots of a wavefront depend on
+     * no other wavefront's, so a wave walks through the ticks of a wcqp_tick_run call on its own - no launch, ramp-up or tail
+     * per tick, and a wave whose robots walk a long active set falls behind without holding anybody up.
+     * 0 -> all the ticks of a wcqp_tick_run call in one launch; k > 0: at most k per launch; 1 = one launch per tick (what
+     * `use_graph` then replays from a hipGraph of 8 ticks).  Same results whatever the value. */
+    int32_t ticks_per_launch;
 } wcqp_tick_params;
 
 typedef struct wcqp_tick_inputs {   /* HOST pointers, copied at upload */
@@ -402,7 +421,8 @@ typedef struct wcqp_tick_s* wcqp_tick_t;
 int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out);
 int wcqp_tick_destroy(wcqp_tick_t h);
 int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in);                 /* also rewinds to tick 0 */
-/* enqueue only; use_graph: hipGraph replays of 8 ticks each, remainder as plain launches.  WCQP_E_INVALID when the ticks
+/* enqueue only; use_graph: hipGraph replays of 8 ticks each, remainder as plain launches (ignored when the fused kernel runs
+ * several ticks per launch: wcqp_tick_params.ticks_per_launch).  WCQP_E_INVALID when the ticks
  * enqueued since the last upload + n_ticks would exceed max_ticks (the trajectories end there). */
 int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream);
 int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out);             /* synchronises     */

@@ -5,6 +5,7 @@
 //   driver parse <mpc.ini> <ik.ini>     CPU only: config parsing, error paths, hull builder
 //   driver mpc   <mpc.ini>              needs a GPU
 //   driver ik    <ik.ini> <form>        needs a GPU (form: osqp | qpoases)
+//   driver config1 <mpc.ini>            needs a GPU: SURVEY.md 8d config 1 (BASELINE configs[0]) through WalkingController, batch of one
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -82,6 +83,30 @@ static int run_mpc(const char* mpcIni) {
     return 0;
 }
 
+// SURVEY.md 8d config 1 / BASELINE configs[0]: ONE DCM-MPC QP, N = 50, single support at identity (n_c = 4),
+// x0 = (0.01, -0.005), reference = straight-line DCM from (0, 0) advancing 0.002 m per stage in x, u_prev = (0, 0) -
+// the per-robot call sequence of WM/src/WalkingModule.cpp:604-636 through the mirrored class: a batch of one on the GPU.
+static int run_config1(const char* mpcIni) {
+    Searchable cfg; cfg.fromConfigText(slurp(mpcIni));
+    WalkingController c;
+    if (!c.initialize(cfg)) return 2;
+    const int N = (int)std::lround(cfg.find("controllerHorizon").asDouble() / cfg.find("sampling_time").asDouble());
+    std::deque<Vector2> dcm;
+    for (int i = 0; i <= N; ++i) { Vector2 r; r(0) = 0.002 * i; r(1) = 0.0; dcm.push_back(r); }
+    std::deque<Transform> dl{makeT(0.0, 0.0, 0.0)}, dr{makeT(0.0, -0.16, 0.0)};
+    std::deque<bool> lc{true}, rc{false};
+    Vector2 x; x(0) = 0.01; x(1) = -0.005;
+    bool ok = c.setConvexHullConstraint(dl, dr, lc, rc);
+    ok = ok && c.setFeedback(x);
+    ok = ok && c.setReferenceSignal(dcm, true);
+    const bool solved = ok && c.solve();
+    Vector2 u; const bool got = solved && c.getControllerOutput(u);
+    std::printf("tick: 0 %d %d %d %u\n", (int)solved, (int)got, c.lastStatus, c.lastActive);
+    line("hull_A", c.hull().A.data(), c.hull().A.rows() * 2); line("hull_b", c.hull().b.data(), c.hull().b.size());
+    if (got) line("u0", u.v, 2);
+    return 0;
+}
+
 static int run_ik(const char* ikIni, const char* form) {
     Searchable cfg; cfg.fromConfigText(slurp(ikIni));
     const bool osqp = std::strcmp(form, "osqp") == 0;
@@ -140,6 +165,7 @@ int main(int argc, char** argv) {
     if (argc >= 4 && !std::strcmp(argv[1], "parse")) return run_parse(argv[2], argv[3]);
     if (argc >= 3 && !std::strcmp(argv[1], "mpc")) return run_mpc(argv[2]);
     if (argc >= 4 && !std::strcmp(argv[1], "ik")) return run_ik(argv[2], argv[3]);
+    if (argc >= 3 && !std::strcmp(argv[1], "config1")) return run_config1(argv[2]);
     std::fprintf(stderr, "usage: driver parse <mpc.ini> <ik.ini> | mpc <mpc.ini> | ik <ik.ini> <form>\n");
     return 1;
 }

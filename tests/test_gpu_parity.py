@@ -458,3 +458,17 @@ def test_qp_enqueue_steps_equals_the_single_calls():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "enqueue_steps_check.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "enqueue_steps ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_timed_launch_shape_against_goldens():
+    """The launch shape bench.py times: BASELINE batch 4096, the bench's own inputs (MPC seed 1234 = golden
+    mpc_cfg2_b4096, IK seed 4321 at v_max 0.5 = golden ik_qpoases_v050_b1024), 12 records handed over in ONE
+    wcqp_qp_enqueue_steps call, spread over three streams that share ONE wcqp_mpc_t / wcqp_ik_t pair (three batches in
+    flight, each record the one-launch step qp_pair_kernel), inputs rotated per record like the bench's input sets; every
+    record's outputs against the goldens (tests/helpers/timed_shape_check.py; a process of its own because torch brings its
+    own HIP runtime and has to initialise before libwcqp's does)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "timed_shape_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "timed shape ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

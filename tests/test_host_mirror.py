@@ -128,6 +128,23 @@ def test_walking_controller_tick_sequence(tmp_path, qs):
 
 
 @pytest.mark.gpu
+def test_survey_config1_through_the_walking_controller(tmp_path, qs):
+    """SURVEY.md 8d config 1 (BASELINE configs[0]) - one MPC QP, N = 50, single support at identity, x0 = (0.01, -0.005),
+    2 mm per stage of reference in x, u_prev = 0 - through wc::WalkingController (a batch of ONE on the GPU: the repo has no
+    CPU path by design) against the exact optimum of the same instance (tests/test_cpu_oracle.py runs it on the oracle alone)."""
+    (r,) = _run(tmp_path, "config1", "@mpc")
+    _, solved, got, status, active = r["tick"].astype(int)
+    assert solved == 1 and got == 1 and status == 0
+    hA, hb = r["hull_A"].reshape(-1, 2), r["hull_b"]
+    assert hA.shape == (4, 2) and sorted(np.round(hb, 12)) == [0.02, 0.025, 0.025, 0.05]      # the foot rectangle of controllerParams.ini:7
+    c = qs.mpc_constants(qs.MPCParams())
+    ref = np.stack([0.002 * np.arange(51), np.zeros(51)], 1)
+    ex = qs.mpc_exact(c, [0.01, -0.005], ref, [0.0, 0.0], hA, hb)
+    assert np.abs(r["u0"] - ex["u0"]).max() <= 1e-12
+    assert int(active) == sum(1 << e for e in ex["active"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["qpoases", "osqp"])
 def test_walking_qpik_tick_sequence(tmp_path, qs, form):
     recs = _run(tmp_path, "ik", "@ik", form)

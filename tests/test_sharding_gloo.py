@@ -163,3 +163,45 @@ def test_two_ranks_on_the_gpu_match_single_process(wca, exchange):
     assert np.array_equal(got["dq"], oi["dq"]) and np.array_equal(got["status"], oi["status"])           # bitwise
     assert np.array_equal(got["up"], oi["active_upper"]) and np.array_equal(got["lo"], oi["active_lower"])
     assert np.array_equal(got["u0"], om["u0"]) and np.array_equal(got["mstatus"], om["status"])
+
+
+def _run_bench(extra_args, env_extra, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_with_one_rank():
+    """The RCCL branch of bench.py (backend "nccl" IS RCCL on ROCm) executed on the one-GPU box: a launcher-style environment
+    with WORLD_SIZE = 1 makes bench.py initialise the process group on the device, scatter the inputs / gather the solutions
+    every step (--exchange), all-reduce the timing and destroy the group - everything the N-GPU run does, with one rank."""
+    env = dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WCQP_DIST_BACKEND="nccl")
+    r, line = _run_bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "512", "--exchange", "--no-cpu-baseline"], env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 1 and "RCCL scatter/gather" in line["config"]["parallelism"]
+    assert line["solved"]["ik"] == 512 and line["solved"]["mpc"] == 512
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (the parent never touches the GPU) and reports
+    n_gpus = 2; on this one-GPU box that is only allowed as a gloo REHEARSAL, and refused otherwise."""
+    args = ["--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "512", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600,
+                       env=dict(env, WCQP_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024
+    sys.path.insert(0, ROOT)
+    import walking_controllers_amd as wca
+    if wca.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600,
+                           env=dict(env, WCQP_DIST_BACKEND="nccl"))
+        assert r.returncode != 0 and "one rank per GPU" in (r.stderr + r.stdout)

@@ -40,7 +40,10 @@ def test_tick_pipeline_matches_cpu_restatement(wca, qs, ik_algorithm):
     ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax * np.ones(23)))
     assert ref["mpc_fail"].sum() == 0 and ref["ik_fail"].sum() == 0
     for use_graph in (False, True):
-        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm), log_ticks=T)
+        # plain launches / hipGraph replay of one-tick launches; the fused kernel's default (the whole run in ONE launch, a wave
+        # walking through the ticks on its own) is the third form below
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm), log_ticks=T,
+                                ticks_per_launch=1)
         pipe.upload(d)
         pipe.run(T, use_graph=use_graph)
         out = pipe.download()
@@ -54,6 +57,16 @@ def test_tick_pipeline_matches_cpu_restatement(wca, qs, ik_algorithm):
             eager = out
     assert np.array_equal(out["u0_log"], eager["u0_log"]) and np.array_equal(out["dq_log"], eager["dq_log"])   # graph == eager, bitwise
     assert np.abs(ref["dq_log"]).max() == pytest.approx(vmax, abs=1e-12)        # velocity limits really bind
+    # several ticks per launch (0: all of a run() call; 7: launches of 7, 7, ... and a remainder), split over two run() calls
+    for k in (0, 7):
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm), log_ticks=T,
+                                ticks_per_launch=k)
+        pipe.upload(d)
+        pipe.run(61); pipe.run(T - 61)
+        multi = pipe.download()
+        assert multi["tick"] == T
+        for key in ("u0_log", "dq_log", "q_des", "dcm", "com", "ik_fail", "mpc_fail", "hot_try", "hot_hit"):
+            assert np.array_equal(multi[key], eager[key]), (k, key)
 
 
 @pytest.mark.gpu
@@ -218,3 +231,68 @@ def test_ik_hot_start_matches_cold_start_and_falls_back(wca):
     assert tries > 0.005 * B * T                      # bounds bind on a share of the robot-ticks here (1.4 % at v_max 0.45)
     assert hits > 0.8 * tries                         # ... and mostly stay the same from one tick to the next
     assert hits < tries                               # the fall-back really ran
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kin_mode", [True, False], ids=["kinematics", "constant_jacobians"])
+def test_tick_at_the_benchmark_geometry(wca, qs, kin_mode):
+    """BASELINE configs 4/5 at their per-GPU size as bench.py runs them: 8192 robots, cut into three robot
+    groups, each a pipeline on a HIP stream of its own, 64 ticks.  No oracle finishes this size in seconds, so the checks are
+    the size-independent properties: no QP fails, every joint velocity respects its limit and the ones the solver reports
+    active sit exactly on it, the three groups reproduce one full-batch pipeline bit for bit (shard == full), and a sample
+    of robots matches oracle/tick_spec.py over the first ticks."""
+    B, T, L = 8192, 64, 8
+    S = wca.synth
+    cuts = [B * k // 3 for k in range(4)]
+    if kin_mode:
+        vmax = S.WALK_VMAX
+        mk_ik = lambda: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, joint_reg_rad=np.deg2rad(S.WALK_POSTURE_DEG))
+        kin = wca.KinModel(S.icub_like_model())
+
+        def data(first, cnt):
+            kb = S.synth_walk_kin_batch(cnt, first=first)
+            poses = kin.jacobians_host(kb["base"], kb["q"], state=np.zeros((cnt, 87)))["state"]
+            return S.synth_walk_batch(cnt, T, poses, kb, first=first)
+    else:
+        vmax = 0.5 * np.ones(23)
+        mk_ik = lambda: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.5)
+        kin = None
+        data = lambda first, cnt: S.synth_tick_batch(cnt, T, first=first)
+
+    def run(first, cnt, stream=0):
+        d = data(first, cnt)
+        pipe = wca.TickPipeline(cnt, T, wca.MpcSolver(), mk_ik(), first=first, log_ticks=L, kin=kin)
+        pipe.upload(d)
+        return d, pipe
+    groups = [run(cuts[k], cuts[k + 1] - cuts[k]) for k in range(3)]
+    streams = [wca.capi.stream_create() for _ in range(3)]
+    wca.capi.stream_synchronize()
+    for (d, pipe), st in zip(groups, streams):
+        pipe.run(T, use_graph=True, stream=st)          # the three groups are in flight together
+    outs = [pipe.download() for _, pipe in groups]
+    for st in streams:
+        wca.capi.stream_destroy(st)
+    cat = lambda k: np.concatenate([o[k] for o in outs], axis=(1 if k.endswith("_log") else 0))
+    assert all(o["tick"] == T for o in outs) and cat("mpc_fail").sum() == 0
+    fails = cat("ik_fail")
+    assert (fails > 0).sum() <= (0 if kin_mode else 2)         # the walk does not fall; a random constant-Jacobian robot may be infeasible
+    dq = cat("dq_log")
+    assert (np.abs(dq) <= vmax + 1e-12).all()
+    on = np.isclose(np.abs(dq), vmax, rtol=0, atol=1e-12)
+    assert on.any() and (np.abs(dq)[on] == np.broadcast_to(vmax, dq.shape)[on]).all()          # active bounds are tight, exactly
+    # shard == full, bit for bit
+    dfull, pfull = run(0, B)
+    pfull.run(T, use_graph=True)
+    full = pfull.download()
+    for k in ("u0_log", "dq_log", "q_des", "dcm", "com", "ik_fail"):
+        assert np.array_equal(cat(k), full[k]), k
+    # a sample of robots (and every robot that failed) through the CPU restatement, first L ticks
+    from oracle import tick_spec as ts
+    sample = sorted(set([0, 1, cuts[1] - 1, cuts[1], cuts[2], B - 1]) | set(np.flatnonzero(fails)[:2].tolist()))
+    for i in sample:
+        one = {k: (v[i:i + 1] if isinstance(v, np.ndarray) else v) for k, v in dfull.items()}
+        one["first"] = int(i)
+        ipar = qs.IKParams(v_max=np.asarray(vmax, float).copy(), **({"joint_reg_deg": S.WALK_POSTURE_DEG.copy()} if kin_mode else {}))
+        ref = ts.run_ticks(ts.TickParams(), one, L, ipar, **({"kin_model": S.icub_like_model(), "foot_rect": S.FOOT_RECT} if kin_mode else {}))
+        assert np.abs(full["u0_log"][:, i] - ref["u0_log"][:, 0]).max() <= 1e-9, i
+        assert np.abs(full["dq_log"][:, i] - ref["dq_log"][:, 0]).max() <= 1e-8, i

@@ -28,7 +28,7 @@ IK_STATE_LEN = 87
 
 # every symbol include/wcqp.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "wcqp_strerror", "wcqp_version", "wcqp_device_count",
+    "wcqp_strerror", "wcqp_version", "wcqp_device_count", "wcqp_stream_create", "wcqp_stream_destroy", "wcqp_stream_synchronize",
     "wcqp_mpc_create", "wcqp_mpc_destroy", "wcqp_mpc_get_condensed", "wcqp_mpc_get_matrices",
     "wcqp_mpc_solve_device", "wcqp_mpc_solve_host",
     "wcqp_ik_create", "wcqp_ik_destroy", "wcqp_ik_set_posture", "wcqp_ik_solve_device", "wcqp_ik_solve_host",
@@ -97,7 +97,7 @@ class TickParams(C.Structure):
                 ("k_com", C.c_double), ("k_zmp", C.c_double), ("noise", C.c_double), ("seed", C.c_uint64),
                 ("mpc", MpcParams), ("ik", IkParams),
                 ("ik_cold_start_only", C.c_int32), ("use_kinematics", C.c_int32), ("kin", KinParams), ("foot_rect", C.c_double * 8),
-                ("kin_dense_handoff", C.c_int32)]
+                ("kin_dense_handoff", C.c_int32), ("ticks_per_launch", C.c_int32)]
 
 
 class TickInputs(C.Structure):
@@ -123,6 +123,9 @@ def lib() -> C.CDLL:
         dp, ip, up, vp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
         L.wcqp_strerror.restype = C.c_char_p
         L.wcqp_strerror.argtypes = [C.c_int]
+        L.wcqp_stream_create.argtypes = [C.POINTER(C.c_void_p)]
+        L.wcqp_stream_destroy.argtypes = [C.c_void_p]
+        L.wcqp_stream_synchronize.argtypes = [C.c_void_p]
         L.wcqp_mpc_create.argtypes = [C.POINTER(MpcParams), C.POINTER(C.c_void_p)]
         L.wcqp_mpc_destroy.argtypes = [C.c_void_p]
         L.wcqp_mpc_get_condensed.argtypes = [C.c_void_p, dp, dp, dp, dp]
@@ -359,7 +362,8 @@ class TickPipeline:
 
     def __init__(self, batch, max_ticks, mpc: MpcSolver, ik: IkSolver, first=0, log_ticks=0,
                  step_ticks=180, ds_ticks=110, k_com=9.0, k_zmp=3.0, noise=1e-4, seed=99,
-                 kin: "Optional[KinModel]" = None, foot_rect=None, ik_hot_start: bool = True, kin_dense_handoff: bool = False):
+                 kin: "Optional[KinModel]" = None, foot_rect=None, ik_hot_start: bool = True, kin_dense_handoff: bool = False,
+                 ticks_per_launch: int = 0):
         """kin: a KinModel -> per-tick kinematics (Jacobians, actual poses and hull rows rebuilt every tick from the
         integrated joint state with the base anchored at the stance foot; upload() then ignores J_* / hull_tab_*)."""
         self.batch, self.max_ticks, self.log_ticks, self.dof = batch, max_ticks, log_ticks, ik.dof
@@ -369,7 +373,7 @@ class TickPipeline:
             foot_rect = FOOT_RECT
         self.params = TickParams(batch, first, max_ticks, log_ticks, step_ticks, ds_ticks, k_com, k_zmp, noise, seed,
                                  mpc.params, ik.params, int(not ik_hot_start), int(self.use_kin), kin.params if kin is not None else KinParams(),
-                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(bool(kin_dense_handoff)))
+                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(bool(kin_dense_handoff)), int(ticks_per_launch))
         self._h = C.c_void_p()
         check(lib().wcqp_tick_create(C.byref(self.params), C.byref(self._h)), "wcqp_tick_create")
         self._keep = None
@@ -412,3 +416,18 @@ class TickPipeline:
 
 def device_count() -> int:
     return int(lib().wcqp_device_count())
+
+
+def stream_create() -> int:
+    """A HIP stream (raw handle as an int) from the library's own runtime - for callers without torch."""
+    s = C.c_void_p()
+    check(lib().wcqp_stream_create(C.byref(s)), "wcqp_stream_create")
+    return s.value
+
+
+def stream_destroy(stream: int) -> None:
+    check(lib().wcqp_stream_destroy(C.c_void_p(stream)), "wcqp_stream_destroy")
+
+
+def stream_synchronize(stream: int = 0) -> None:
+    check(lib().wcqp_stream_synchronize(C.c_void_p(stream) if stream else None), "wcqp_stream_synchronize")

@@ -109,4 +109,24 @@ int wcqp_device_count(void) {
     return n;
 }
 
+int wcqp_stream_create(void** out) {
+    if (!out) return WCQP_E_INVALID;
+    hipStream_t s = nullptr;
+    WCQP_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = s;
+    return WCQP_OK;
+}
+
+int wcqp_stream_destroy(void* stream) {
+    if (!stream) return WCQP_E_INVALID;
+    WCQP_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return WCQP_OK;
+}
+
+int wcqp_stream_synchronize(void* stream) {
+    if (stream) WCQP_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    else WCQP_HIP_TRY(hipDeviceSynchronize());
+    return WCQP_OK;
+}
+
 }  // extern "C"

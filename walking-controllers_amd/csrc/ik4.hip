@@ -117,9 +117,14 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* qpos, const double* __restrict__ state,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
-                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td, double (*smem)[PER_INST], int blk)
+                double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev& td, double (*smem)[PER_INST], int blk,
+                const int tick_now = 0)
 {
-    const int lane = threadIdx.x;
+    int lane_id = threadIdx.x;
+    // inside the tick kernel's loop over ticks: keeps hipcc from hoisting every per-lane address and constant of the body
+    // out of the loop (they would all be live across the whole body: +100 VGPRs and spills)
+    if constexpr (TICK) __asm__ volatile("" : "+v"(lane_id));
+    const int lane = lane_id;
     const int grp = lane >> 4;
     const int j = lane & 15;
     const long inst_raw = (long)blk * 4 + grp;
@@ -133,11 +138,9 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     const bool base1 = j >= 8 && j < 14;            // slot 1 is base column j - 8
     const int col1 = j + 16;
 
-    int tick_now = 0;
     unsigned prev_lo = 0u, prev_up = 0u;            // hot start: the previous tick's active bounds of this instance
     bool stopped = false;                           // tick pipeline: the robot's IK failed on an earlier tick (tick_device.h)
     if constexpr (TICK) {
-        tick_now = td.tick2[td.phase];
         if (td.hot_start && alo_out && aup_out) { prev_lo = alo_out[inst]; prev_up = aup_out[inst]; }
         stopped = wcqp_tick::tick_robot_stopped(td, (int)inst);
         if (stopped) { prev_lo = 0u; prev_up = 0u; }
@@ -1047,8 +1050,6 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             if (var1) wcqp_tick::tick_post_joint(td, i_, tick_now, col1, ik_ok, dq1);
             if (j == 0 && (!ik_ok || stopped)) td.ik_fail[i_] += 1;       // tick_post_instance without the contact pair: the MPC part derives its own
         }
-        // advanceReferenceSignals (WalkingModule.cpp:816): the next tick reads the other copy of the tick index
-        if (blk == 0 && lane == 0) td.tick2[1 - td.phase] = tick_now + 1;
     }
     if (ferr_out) {
         // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401) with nu = (v_base, dq) and
@@ -1095,6 +1096,11 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     }
 }
 
+// n_inner (tick pipeline): ticks this launch runs.  The robots of a wave depend on no other wave's - the launch of a tick
+// is not a synchronisation point anybody needs - so a wave walks through n_inner ticks on its own: what tick t leaves in
+// memory for tick t + 1 (joint state, hand-off record, previous active set, live hull rows) is written and read by the
+// same wave, ordered by a workgroup-scope fence per tick.  No per-tick launch, no ramp-up / tail per tick, and a wave
+// whose robots walk a long active set on one tick catches up on the next instead of holding the whole launch.
 template <bool TICK, bool COMPACT>
 __global__ __launch_bounds__(64, WCQP_IK4_WAVES)
 void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
@@ -1103,10 +1109,30 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* qpos, const double* __restrict__ state,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
-                double* __restrict__ ferr_out, int* __restrict__ iters_out, wcqp_tick::TickDev td)
+                double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev* __restrict__ tdp, int phase, int n_inner)
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
-    ik4_body<TICK, COMPACT>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem, (int)blockIdx.x);
+    if constexpr (TICK) {
+        // TickDev lives in device memory, not in the kernel arguments: hipcc hoists kernel-argument loads out of the loop over
+        // ticks as invariant (a hundred SGPRs live across the whole body, spilled to VGPR lanes); loads through this pointer
+        // stay where they are used (memory clobber at the top of an iteration)
+        const wcqp_tick::TickDev& td = *tdp;
+        const int t0 = td.tick2[phase];
+#pragma unroll 1
+        for (int k = 0; k < n_inner; ++k) {
+            __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop (its registers are all spoken for)
+            ik4_body<TICK, COMPACT>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
+                                    (int)blockIdx.x, t0 + k);
+            // tick t + 1 of this wave reads what tick t wrote (other lanes of the same wave): visible before it starts
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        // advanceReferenceSignals (WalkingModule.cpp:816): the next launch reads the other copy of the tick index
+        if (blockIdx.x == 0 && threadIdx.x == 0) td.tick2[1 - phase] = t0 + n_inner;
+    } else {
+        ik4_body<TICK, COMPACT>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem, (int)blockIdx.x);
+    }
 }
 
 // The MPC chain of ONE tick for every robot, on its own: primes the skewed tick after an upload (MPC(0) has to have run
@@ -1198,23 +1224,24 @@ int ik4_launch(const IkDeviceParams* d_prm, int batch,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
     const unsigned grid = (unsigned)((batch + 3) / 4);
     hipLaunchKernelGGL((ik4_kernel<false, false>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
-                       dq, status, alo, aup, ferr, iters, wcqp_tick::TickDev{});
+                       dq, status, alo, aup, ferr, iters, nullptr, 0, 1);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }
 
-int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
+int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_tick::TickDev* td_dev,
                     const double* JL, const double* JR, const double* JN, const double* JC,
-                    unsigned* alo, unsigned* aup, hipStream_t stream) {
-    if (!d_prm || !td.skew || !td.mst || !td.hand || !td.live_A || !td.live_b || !td.live_nc || !td.sel_built) return WCQP_E_INVALID;
+                    unsigned* alo, unsigned* aup, int n_inner, hipStream_t stream) {
+    if (n_inner < 1 || (n_inner > 1 && td.kin_mode)) return WCQP_E_INVALID;      // with per-tick kinematics the Jacobians of tick t + 1 come from another launch
+    if (!d_prm || !td_dev || !td.skew || !td.mst || !td.hand || !td.live_A || !td.live_b || !td.live_nc || !td.sel_built) return WCQP_E_INVALID;
     if (td.compact && (!td.jcomp || td.cstride < 1)) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((td.batch + 3) / 4);
     if (td.compact)
         hipLaunchKernelGGL((ik4_kernel<true, true>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
-                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td);
+                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner);
     else
         hipLaunchKernelGGL((ik4_kernel<true, false>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
-                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td);
+                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }

@@ -391,9 +391,11 @@ int ik4_launch_pair(const IkDeviceParams* d_prm, int batch,
                     double* u0, int* mstatus, unsigned* mactive, double* mmargin, hipStream_t stream);
 // the base-eliminated kernel with the SKEWED tick fused in: IK(t) + post step of tick t and the MPC chain of tick t + 1
 // (tick_device.h); dense Jacobians, or the compact per-joint records of the tick's own kinematics kernel (td.compact)
-int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td,
+// n_inner: ticks per launch (> 1 only without per-tick kinematics); td_dev: the same TickDev in device memory (td.phase is
+// passed as a kernel argument, the copy's is not read)
+int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_tick::TickDev* td_dev,
                     const double* JL, const double* JR, const double* JN, const double* JC,
-                    unsigned* alo, unsigned* aup, hipStream_t stream);
+                    unsigned* alo, unsigned* aup, int n_inner, hipStream_t stream);
 // the MPC chain of tick t alone: primes the skewed tick after an upload
 int ik4_launch_tick_prime(const wcqp_tick::TickDev& td, int t, hipStream_t stream);
 }  // namespace wcqp_ik

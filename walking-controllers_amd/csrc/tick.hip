@@ -57,6 +57,7 @@ struct wcqp_tick_s {
     wcqp_mpc_t mpc = nullptr;
     wcqp_ik_t ik = nullptr;
     TickDev d{};
+    TickDev* d_dev = nullptr;     // copy of `d` in device memory (the fused kernel reads it from there, see ik4.hip)
     std::vector<void*> allocs;
     double *J_left = nullptr, *J_right = nullptr, *J_neck = nullptr, *J_com = nullptr;
     unsigned* mpc_active = nullptr; double* mpc_margin = nullptr;
@@ -71,6 +72,8 @@ struct wcqp_tick_s {
     wcqp_kin_t kin = nullptr;     // use_kinematics: Jacobians, actual poses and hull rows are rebuilt every tick
     KinTick kt{};
     bool primed = false;          // skewed tick: MPC(ticks_enqueued) has run (the fused launch of tick t carries IK(t) and MPC(t+1))
+    int phase = 0;                // which copy of the tick index the next launch reads (TickDev::tick2): toggles per LAUNCH
+    int ticks_per_launch = 1;     // > 1: the fused kernel walks through that many ticks per launch (no per-tick kinematics)
 };
 
 namespace {
@@ -85,12 +88,14 @@ int dev_alloc(wcqp_tick_s* h, T** out, size_t count) {
     return WCQP_OK;
 }
 
-// one tick with the given phase (= parity of the tick index: see TickDev::tick2)
-int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s) {
+// one launch sequence of n_inner ticks (n_inner > 1: the fused base-eliminated kernel without per-tick kinematics only) with
+// the given phase (which copy of the tick index it reads: see TickDev::tick2)
+int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s, int n_inner = 1) {
     TickDev d = h->d;
     d.phase = phase & 1;
     const int B = d.batch;
     const int N = wcqp::mpc_horizon(h->mpc);
+    if (n_inner > 1 && !(h->fused && h->base_elim && !h->kin)) return WCQP_E_INVALID;
     if (h->kin) {
         h->kt.phase = d.phase;
         const int rck = wcqp::kin_enqueue_tick(h->kin, B, h->kt, d.q_des, h->J_left, h->J_right, h->J_neck, h->J_com, d.state, s);
@@ -98,8 +103,8 @@ int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s) {
     }
     // base-eliminated IK kernel: IK + post step of this tick and MPC + glue + plant of the NEXT one in ONE launch (skewed tick)
     if (h->fused && h->base_elim)
-        return wcqp_ik::ik4_launch_tick(wcqp::ik_device_params(h->ik), d, h->J_left, h->J_right, h->J_neck, h->J_com,
-                                        h->ik_lo, h->ik_up, s);
+        return wcqp_ik::ik4_launch_tick(wcqp::ik_device_params(h->ik), d, h->d_dev, h->J_left, h->J_right, h->J_neck, h->J_com,
+                                        h->ik_lo, h->ik_up, n_inner, s);
     int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick2 + d.phase, d.u_prev,
                                d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, d.hull_sets, d.hull_sets > 1 ? d.sel : nullptr,
                                d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
@@ -150,6 +155,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     // the tick's Jacobians are MIXED free-floating ones (uploaded or from wcqp_kin_*): an instance that is not comes
     // back WCQP_STATUS_STRUCTURE and counts as an IK failure
     h->d.hot_start = params->ik_cold_start_only ? 0 : 1;
+    if (params->ticks_per_launch < 0) { wcqp_tick_destroy(h); return WCQP_E_INVALID; }
     h->base_elim = h->fused && params->ik.algorithm != WCQP_IK_ALG_NULLSPACE_16L &&
                    params->ik.jacobian_structure != WCQP_IK_JAC_GENERAL && wcqp::ik_fast_ok(h->ik);
     const size_t B = (size_t)params->batch;
@@ -179,6 +185,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     A_(h->mpc_active, B); A_(h->mpc_margin, B); A_(h->ik_lo, B); A_(h->ik_up, B);
     // skewed tick (base-eliminated fused kernel): state of the MPC chain, MPC -> IK hand-off, one live hull row set per robot
     d.skew = (h->fused && h->base_elim) ? 1 : 0;
+    h->ticks_per_launch = (d.skew && !h->kin) ? (params->ticks_per_launch > 0 ? params->ticks_per_launch : (1 << 20)) : 1;
     double* jcomp = nullptr;
     unsigned cm[3] = {0u, 0u, 0u};
     int cstride = 0, coff_d = 0;
@@ -200,6 +207,10 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
         if (compact) { h->kt.jcomp = jcomp; h->kt.cstride = cstride; h->kt.coff_d = coff_d; }
     }
     d.ref_traj = ref; d.hull_tab_A = hA; d.hull_tab_b = hb; d.hull_tab_nc = hn; d.phase0 = ph; d.swing_twist = sw;
+    if (d.skew) {
+        if (dev_alloc(h, &h->d_dev, 1) != WCQP_OK) { wcqp_tick_destroy(h); return WCQP_E_NOMEM; }
+        if (hipMemcpy(h->d_dev, &d, sizeof(TickDev), hipMemcpyHostToDevice) != hipSuccess) { wcqp_tick_destroy(h); return WCQP_E_HIP; }
+    }
     *out = h;
     return WCQP_OK;
 }
@@ -280,6 +291,7 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     h->uploaded = true;
     h->ticks_enqueued = 0;
     h->primed = false;
+    h->phase = 0;
     return WCQP_OK;
 }
 
@@ -294,17 +306,27 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         if (rc != WCQP_OK) return rc;
         h->primed = true;
     }
+    int left = n_ticks;
+    // the fused kernel walks through several ticks per launch (the waves need no per-tick synchronisation): no graph needed
+    if (h->ticks_per_launch > 1) {
+        while (left > 0) {
+            const int k = left < h->ticks_per_launch ? left : h->ticks_per_launch;
+            const int rc = enqueue_tick(h, h->phase, s, k);
+            if (rc != WCQP_OK) return rc;
+            h->phase ^= 1; h->ticks_enqueued += k; left -= k;
+        }
+        return WCQP_OK;
+    }
     // kGraphTicks ticks per graph (the tick index lives in HBM, so the graph is tick-invariant): one
     // hipGraphLaunch costs about as much as four plain launches.  The graph is captured with phases 0, 1, 0, ...
-    // and therefore replayed only from an even tick index; an odd one takes a plain tick first.
+    // and therefore replayed only from phase 0; from phase 1 a plain tick goes first.
     constexpr int kGraphTicks = 8;
-    int left = n_ticks;
     auto plain = [&]() -> int {
-        const int rc = enqueue_tick(h, h->ticks_enqueued & 1, s);
-        if (rc == WCQP_OK) { ++h->ticks_enqueued; --left; }
+        const int rc = enqueue_tick(h, h->phase, s);
+        if (rc == WCQP_OK) { h->phase ^= 1; ++h->ticks_enqueued; --left; }
         return rc;
     };
-    if (use_graph && left >= kGraphTicks + 1 && (h->ticks_enqueued & 1)) { const int rc = plain(); if (rc != WCQP_OK) return rc; }
+    if (use_graph && left >= kGraphTicks + 1 && h->phase) { const int rc = plain(); if (rc != WCQP_OK) return rc; }
     if (use_graph && !h->graph_exec && left >= kGraphTicks) {
         hipStream_t cs = nullptr;
         WCQP_HIP_TRY(hipStreamCreate(&cs));
@@ -320,7 +342,7 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         h->graph = g;
         WCQP_HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
     }
-    if (use_graph && h->graph_exec && !(h->ticks_enqueued & 1)) {
+    if (use_graph && h->graph_exec && !h->phase) {
         for (; left >= kGraphTicks; left -= kGraphTicks, h->ticks_enqueued += kGraphTicks) WCQP_HIP_TRY(hipGraphLaunch(h->graph_exec, s));
     }
     while (left > 0) { const int rc = plain(); if (rc != WCQP_OK) return rc; }
@@ -351,7 +373,7 @@ int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
         DN_(out->dcm, d.dcm, B * 16); DN_(out->com, d.com, B * 16);
     }
     DN_(out->mpc_fail, d.mpc_fail, B * 8); DN_(out->ik_fail, d.ik_fail, B * 8);
-    DN_(out->hot_try, d.hot_try, B * 8); DN_(out->hot_hit, d.hot_hit, B * 8); DN_(out->tick, d.tick2 + (h->ticks_enqueued & 1), 4);
+    DN_(out->hot_try, d.hot_try, B * 8); DN_(out->hot_hit, d.hot_hit, B * 8); DN_(out->tick, d.tick2 + h->phase, 4);
 #undef DN_
     return WCQP_OK;
 }
