@@ -85,6 +85,9 @@ def main():
                     "solve kernel instead of the compact per-joint records (A/B; same results)")
     ap.add_argument("--ticks-per-launch", type=int, default=0, help="tick workload without per-tick kinematics: ticks the fused kernel runs per launch (0 = the library's default, 1 = one launch per tick)")
     ap.add_argument("--tick-cold-ik", action="store_true", help="tick workload: no IK hot start (every tick walks the active set from the unconstrained optimum)")
+    ap.add_argument("--step-graph", action="store_true", help="qp workload: replay ONE hipGraph that holds the timed steps as P parallel chains (one per "
+                    "pipeline) instead of enqueueing them launch by launch.  Measured and left off: 8.9-9.2 us per step against 8.5-9.1 in "
+                    "the driver's 20-step form, 8.9 against 7.0 at 200 steps (profiles/r03_step_graph_ab.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     args = ap.parse_args()
@@ -163,7 +166,10 @@ def main():
     ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
     jac = {"mixed": wca.IK_JAC_MIXED, "auto": wca.IK_JAC_AUTO, "general": wca.IK_JAC_GENERAL}[args.ik_jac]
     ik = wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=jac)
-    stream = torch.cuda.current_stream(dev)
+    # pipeline 0 gets a stream of its own as well (a hipGraph cannot be captured on the default stream); the exchange path
+    # stays on the current stream, where torch.distributed enqueues its collectives
+    torch.cuda.synchronize(dev)                    # inputs and zero-filled outputs were enqueued on the default stream
+    stream = torch.cuda.current_stream(dev) if (args.exchange and dist is not None) else torch.cuda.Stream(dev)
     sp = stream.cuda_stream
     # one stream per pipeline: wcqp_qp_enqueue_steps then makes the two calls of a step as ONE launch (IK and MPC workgroups
     # side by side); --streams 2 keeps them as two launches on two streams (the exchange path always does)
@@ -285,9 +291,32 @@ def main():
             r.J_left, r.J_right, r.J_neck, r.J_com, r.q, r.state = q_
             r.dq, r.ik_status, r.active_lower, r.active_upper, r.foot_err, r.iters = o["dq"], o["istat"], o["ilo"], o["iup"], None, o["iit"]
             r.ik_stream = sptr[k][0] or None
+    # --step-graph: the K timed steps as ONE hipGraph - P parallel chains of one-launch steps (pipeline p's steps in order on
+    # its stream, the chains forked from and joined into the capture stream), captured from the very wcqp_qp_enqueue_steps
+    # call the launch-by-launch form makes; set-up: capture, instantiate, one replay (the first launch of a graph uploads
+    # it).  A/B'd in round 3 and left OFF: the graph's dependent kernel nodes are dispatched no faster than the streams do it.
+    step_graph = None
+    if recs is not None and args.step_graph:
+        try:
+            side = [st_ for st_ in all_streams if st_ is not stream]
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                for st_ in side:
+                    st_.wait_stream(stream)
+                wca.capi.qp_enqueue_steps(mpc, ik, B, recs)
+                for st_ in side:
+                    stream.wait_stream(st_)
+            g.replay()
+            barrier()
+            step_graph = g
+        except Exception as e:                      # no graph: the launch-by-launch form still measures the same steps
+            print("bench.py: step graph not available (%r): enqueueing launch by launch" % (e,), file=sys.stderr)
+            torch.cuda.synchronize(dev)
     # ---- the timed region: K steps, nothing but the launches (no events, no host reads) ----------------------------
     t0 = time.perf_counter()
-    if recs is not None:
+    if step_graph is not None:
+        step_graph.replay()
+    elif recs is not None:
         wca.capi.qp_enqueue_steps(mpc, ik, B, recs)
     else:
         for i in range(args.steps):
@@ -397,6 +426,7 @@ def main():
             "batch_per_gpu": B, "global_batch": B * world, "horizon": NH, "dof": 23,
             "input_sets": K, "input_bytes_per_set": set_bytes, "ik_jacobian_structure": args.ik_jac, "pipelines": P,
             "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
+            "timed_steps_enqueued_as": ("one hipGraph launch: %d parallel chains of one-launch steps" % P) if step_graph is not None else "one wcqp_qp_enqueue_steps call, launch by launch",
             "timed_region": "barrier + torch.cuda.synchronize() -> K steps -> completion events of every stream used (hipEventSynchronize), "
                             "MAX over ranks; the device-wide synchronize that follows adds %.0f us of host time with the device idle "
                             "(ms_per_step_incl_device_sync)" % (1e6 * (elapsed_sync - elapsed)),
@@ -444,8 +474,12 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
-            tr = json.load(open(traffic_file)).get("per_batch", {}).get(str(B))
-            if tr:
+            tj = json.load(open(traffic_file))
+            tr = tj.get("per_batch", {}).get(str(B))
+            # only while the kernels are the ones the PMC passes ran on (tools/pmc/make_traffic.py stamps the sources' hash)
+            if tj.get("csrc_sha256") != wca.capi.source_hash():
+                out["roofline"]["traffic_note"] = "profiles/traffic.json was measured on other kernel sources (re-run tools/pmc/collect.sh + make_traffic.py): not quoted"
+            elif tr:
                 out["roofline"]["traffic"] = tr.get("pair_hbm_bytes_per_launch" if pair_mode else "ik_hbm_bytes_per_launch")
         except Exception:
             pass

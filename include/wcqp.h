@@ -425,6 +425,16 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in);                
  * several ticks per launch: wcqp_tick_params.ticks_per_launch).  WCQP_E_INVALID when the ticks
  * enqueued since the last upload + n_ticks would exceed max_ticks (the trajectories end there). */
 int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream);
+/* Trajectory merge (WM/src/WalkingModule.cpp:500-535, 1263-1308: a newly planned trajectory is spliced into the deques at a
+ * merge point - 20 ticks ahead in the shipped configuration - and `resetTrajectory` is raised for exactly one tick): replaces
+ * stages [from_tick, from_tick + n_stages) of every instance's DCM reference trajectory with ref_tail[B][n_stages][2] (HOST
+ * pointer), in stream order behind the ticks already enqueued, while everything else of the pipeline stays as it is; later
+ * ticks see the new stages through their windows [t, t + N].  from_tick >= the ticks enqueued so far, from_tick + n_stages <=
+ * max_ticks + N + 1.  The reset flag itself has no counterpart: it makes MPCSolver::setGradient rebuild the gradient instead of
+ * shifting it (MPCSolver.cpp:188-239), and this library always evaluates the gradient's contribution from the current window.
+ * Valid between wcqp_tick_run calls (a call leaves nothing running ahead); captured graphs stay valid - the trajectory
+ * buffer does not move. */
+int wcqp_tick_splice_reference(wcqp_tick_t h, int32_t from_tick, int32_t n_stages, const double* ref_tail, void* stream);
 int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out);             /* synchronises     */
 
 #ifdef __cplusplus

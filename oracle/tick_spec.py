@@ -84,7 +84,7 @@ def contact_code(t: int, phase0: np.ndarray, p: TickParams) -> np.ndarray:
 
 
 def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, ik_form: str = "qpoases",
-              kin_model: dict | None = None, foot_rect=None):
+              kin_model: dict | None = None, foot_rect=None, splices: dict | None = None):
     """data: the arrays of walking-controllers_amd/synth.py::synth_tick_batch (or synth_walk_batch with
     `kin_model`).  Returns the per-tick logs u0[T][B][2], dq[T][B][23] and the final states.
 
@@ -93,7 +93,16 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
     (:396-410), with the floating base anchored at the stance foot of the current step: world_T_base = desired sole
     pose x (sole pose in the base frame)^-1 (WalkingFK::evaluateWorldToBaseTransformation,
     WM/src/WalkingForwardKinematics.cpp:160-256); the support-polygon rows are rebuilt from the DESIRED foot poses
-    whenever the contact pair changes (...PredictiveController.cpp:364-435)."""
+    whenever the contact pair changes (...PredictiveController.cpp:364-435).
+
+    splices {tick: (from_tick, tail[B][n][2])}: trajectory merges (WM/src/WalkingModule.cpp:500-535, 1263-1308) - before tick
+    `tick` runs, stages [from_tick, from_tick + n) of every instance's DCM reference are replaced by a newly planned tail
+    (the reference splices its deques at a merge point 20 ticks ahead; `resetTrajectory` is raised for that one tick and
+    makes MPCSolver::setGradient rebuild the gradient instead of shifting it, MPCSolver.cpp:188-239 - with the gradient always
+    evaluated from the current window, as here, that flag changes nothing)."""
+    if splices:
+        data = dict(data)
+        data["ref_traj"] = np.array(data["ref_traj"], copy=True)
     B = data["q0"].shape[0]
     N = p.horizon
     mp = qs.MPCParams(horizon=N, sampling_time=p.dT, com_height=p.com_height, gravity=p.gravity)
@@ -113,6 +122,10 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
     J_now = [None] * B
     active_log = []
     for t in range(n_ticks):
+        if splices and t in splices:
+            frm, tail = splices[t]
+            assert frm >= t
+            data["ref_traj"][:, frm:frm + tail.shape[1]] = tail
         code = contact_code(t, data["phase0"], p)
         if use_kin:
             ident = np.concatenate([np.zeros(3), np.eye(3).reshape(9)])

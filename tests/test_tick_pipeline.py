@@ -126,6 +126,49 @@ def test_tick_run_refuses_to_run_past_the_trajectories(wca):
     assert np.array_equal(pipe.download()["dq_log"], want["dq_log"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ticks_per_launch", [0, 1], ids=["whole_call_per_launch", "one_tick_per_launch+graph"])
+def test_trajectory_merge_on_the_device(wca, qs, ticks_per_launch):
+    """SURVEY 8f-1, trajectory merge (WM/src/WalkingModule.cpp:500-535, 1263-1308): a newly planned DCM trajectory is spliced in
+    20 ticks ahead of the running tick while the pipeline keeps its state - twice in 330 ticks (a merge every 150 ticks), between
+    wcqp_tick_run calls.  Same trajectories as oracle/tick_spec.py with the same merges (1e-9), and really different from the
+    run without them; captured graphs stay valid (the trajectory buffer does not move)."""
+    from oracle import tick_spec as ts
+    B, T, vmax = 8, 330, 0.45
+    p = ts.TickParams()
+    d = wca.synth.synth_tick_batch(B, T)
+    N = p.horizon
+    merges = {}
+    for t_m in (130, 280):
+        frm = t_m + 20
+        n = T + N + 1 - frm
+        # the new plan: the old one bent away smoothly by up to 1.5 cm (per-instance direction), continuous at the merge point
+        ramp = 1.0 - np.exp(-np.arange(n) / 40.0)
+        dirn = np.stack([np.cos(0.7 * np.arange(B) + t_m), np.sin(0.7 * np.arange(B) + t_m)], 1)
+        base = merges[130][1][:, 150:] if t_m == 280 else d["ref_traj"][:, frm:]
+        merges[t_m] = (frm, np.ascontiguousarray(base[:, :n] + 0.015 * ramp[None, :, None] * dirn[:, None, :]))
+    ik = lambda: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax)
+    ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax * np.ones(23)), splices=merges)
+    plain = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax * np.ones(23)))
+    assert np.abs(ref["u0_log"] - plain["u0_log"]).max() > 1e-3          # the merges matter
+    pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik(), log_ticks=T, ticks_per_launch=ticks_per_launch)
+    pipe.upload(d)
+    done = 0
+    for t_m in (130, 280):
+        pipe.run(t_m - done, use_graph=True); done = t_m
+        pipe.splice_reference(*merges[t_m])
+    pipe.run(T - done, use_graph=True)
+    out = pipe.download()
+    assert out["tick"] == T and out["mpc_fail"].sum() == 0 and np.array_equal(out["ik_fail"], ref["ik_fail"])
+    assert np.abs(out["u0_log"] - ref["u0_log"]).max() <= 1e-9 and np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8
+    assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9 and np.abs(out["dcm"] - ref["dcm"]).max() <= 1e-9
+    # a merge may not reach into the past, nor beyond the trajectories
+    with pytest.raises(wca.WcqpError):
+        pipe.splice_reference(T - 1, np.zeros((B, 4, 2)))
+    with pytest.raises(wca.WcqpError):
+        pipe.splice_reference(T + N, np.zeros((B, 4, 2)))
+
+
 def _walk_scenario(wca, B, T, first=0):
     """A coherent synthetic robot marching in place (synth_walk_batch): poses from the device kinematics at tick 0."""
     kin = wca.KinModel(wca.synth.icub_like_model())

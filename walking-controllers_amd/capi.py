@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "wcqp_ik_create", "wcqp_ik_destroy", "wcqp_ik_set_posture", "wcqp_ik_solve_device", "wcqp_ik_solve_host",
     "wcqp_hull_from_feet_device", "wcqp_hull_from_feet_host",
     "wcqp_kin_create", "wcqp_kin_destroy", "wcqp_kin_jacobians_device", "wcqp_kin_jacobians_host",
-    "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download",
+    "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download", "wcqp_tick_splice_reference",
     "wcqp_qp_enqueue_steps",
 )
 
@@ -150,6 +150,7 @@ def lib() -> C.CDLL:
         L.wcqp_tick_upload.argtypes = [C.c_void_p, C.POINTER(TickInputs)]
         L.wcqp_tick_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.wcqp_tick_download.argtypes = [C.c_void_p, C.POINTER(TickOutputs)]
+        L.wcqp_tick_splice_reference.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.wcqp_qp_enqueue_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.POINTER(C.c_int32)]
         _lib = L
     return _lib
@@ -403,6 +404,14 @@ class TickPipeline:
     def run(self, n_ticks: int, use_graph: bool = True, stream: int = 0):
         check(lib().wcqp_tick_run(self._h, int(n_ticks), int(bool(use_graph)), stream or None), "wcqp_tick_run")
 
+    def splice_reference(self, from_tick: int, ref_tail, stream: int = 0):
+        """Trajectory merge: stages [from_tick, from_tick + n) of every instance's DCM reference <- ref_tail[B][n][2]."""
+        tail = _f64(ref_tail)
+        assert tail.ndim == 3 and tail.shape[0] == self.batch and tail.shape[2] == 2, tail.shape
+        check(lib().wcqp_tick_splice_reference(self._h, int(from_tick), tail.shape[1], _p(tail), stream or None), "wcqp_tick_splice_reference")
+        if stream:
+            stream_synchronize(stream)          # the host array must outlive the copy
+
     def download(self):
         B, L, D = self.batch, self.log_ticks, self.dof
         o = dict(u0_log=np.zeros((L, B, 2)), dq_log=np.zeros((L, B, D)), q_des=np.zeros((B, D)), dcm=np.zeros((B, 2)),
@@ -412,6 +421,20 @@ class TickPipeline:
         check(lib().wcqp_tick_download(self._h, C.byref(outs)), "wcqp_tick_download")
         o["tick"] = int(o["tick"][0])
         return o
+
+
+def source_hash() -> str:
+    """sha256 over the kernel / ABI sources (csrc/*.hip, *.h, *.cpp and include/wcqp.h): what a measurement that is kept in the
+    repository (profiles/traffic.json) is stamped with, so that it is not quoted for kernels that have changed since."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(os.path.dirname(_HERE), "include", "wcqp.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def device_count() -> int:

@@ -118,7 +118,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev& td, double (*smem)[PER_INST], int blk,
-                const int tick_now = 0)
+                const int tick_now = 0, const bool do_mpc = true)
 {
     int lane_id = threadIdx.x;
     // inside the tick kernel's loop over ticks: keeps hipcc from hoisting every per-lane address and constant of the body
@@ -161,7 +161,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     // behind them, and its arithmetic runs while the Jacobians are in flight; IK(t) reads what MPC(t) left in the hand-off
     // record one launch ago (the first launch after an upload is primed by tick_mpc_prime_kernel, tick.hip).
     wcqp_tick::TickMpcRegs mreg;
-    if constexpr (TICK) wcqp_tick::tick_mpc_issue(td, j, inst, tick_now + 1, mreg);
+    if constexpr (TICK) { if (do_mpc) wcqp_tick::tick_mpc_issue(td, j, inst, tick_now + 1, mreg); else mreg.phase0 = td.phase0[inst]; }
     double2 cr0[5], cr1[5], cdv[5];        // COMPACT: the two joint records and the three vectors p_frame - p_base, as loaded
     int ckind0 = 0, ckind1 = 0;
     {
@@ -218,7 +218,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TICK) {
             // MPC(t+1), ZMP-CoM law and plant of tick t + 1 for the same four robots, while the Jacobians are on their way
-            wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL));
+            if (do_mpc) wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL));
             if (j < 6) {
                 const int code = wcqp_tick::contact_code(tick_now, mreg.phase0, td.step_ticks, td.ds_ticks);
                 const double tw = g_sw * wcqp_tick::swing_profile_at(td, mreg.phase0, tick_now);
@@ -1096,6 +1096,8 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     }
 }
 
+// skip_last_mpc: the last tick of the launch does not run the MPC chain of the tick after it (the last launch of a
+// wcqp_tick_run call: between calls nothing is ahead of anything, so the host may change the trajectories or read the state).
 // n_inner (tick pipeline): ticks this launch runs.  The robots of a wave depend on no other wave's - the launch of a tick
 // is not a synchronisation point anybody needs - so a wave walks through n_inner ticks on its own: what tick t leaves in
 // memory for tick t + 1 (joint state, hand-off record, previous active set, live hull rows) is written and read by the
@@ -1109,7 +1111,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* qpos, const double* __restrict__ state,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
-                double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev* __restrict__ tdp, int phase, int n_inner)
+                double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev* __restrict__ tdp, int phase, int n_inner, int skip_last_mpc)
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
     if constexpr (TICK) {
@@ -1122,7 +1124,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         for (int k = 0; k < n_inner; ++k) {
             __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop (its registers are all spoken for)
             ik4_body<TICK, COMPACT>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
-                                    (int)blockIdx.x, t0 + k);
+                                    (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1));
             // tick t + 1 of this wave reads what tick t wrote (other lanes of the same wave): visible before it starts
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -1224,24 +1226,24 @@ int ik4_launch(const IkDeviceParams* d_prm, int batch,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
     const unsigned grid = (unsigned)((batch + 3) / 4);
     hipLaunchKernelGGL((ik4_kernel<false, false>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
-                       dq, status, alo, aup, ferr, iters, nullptr, 0, 1);
+                       dq, status, alo, aup, ferr, iters, nullptr, 0, 1, 0);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }
 
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_tick::TickDev* td_dev,
                     const double* JL, const double* JR, const double* JN, const double* JC,
-                    unsigned* alo, unsigned* aup, int n_inner, hipStream_t stream) {
+                    unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream) {
     if (n_inner < 1 || (n_inner > 1 && td.kin_mode)) return WCQP_E_INVALID;      // with per-tick kinematics the Jacobians of tick t + 1 come from another launch
     if (!d_prm || !td_dev || !td.skew || !td.mst || !td.hand || !td.live_A || !td.live_b || !td.live_nc || !td.sel_built) return WCQP_E_INVALID;
     if (td.compact && (!td.jcomp || td.cstride < 1)) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((td.batch + 3) / 4);
     if (td.compact)
         hipLaunchKernelGGL((ik4_kernel<true, true>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
-                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner);
+                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
     else
         hipLaunchKernelGGL((ik4_kernel<true, false>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
-                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner);
+                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }

@@ -395,7 +395,7 @@ int ik4_launch_pair(const IkDeviceParams* d_prm, int batch,
 // passed as a kernel argument, the copy's is not read)
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_tick::TickDev* td_dev,
                     const double* JL, const double* JR, const double* JN, const double* JC,
-                    unsigned* alo, unsigned* aup, int n_inner, hipStream_t stream);
+                    unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream);
 // the MPC chain of tick t alone: primes the skewed tick after an upload
 int ik4_launch_tick_prime(const wcqp_tick::TickDev& td, int t, hipStream_t stream);
 }  // namespace wcqp_ik

@@ -71,7 +71,6 @@ struct wcqp_tick_s {
     bool base_elim = false;  // the fused kernel is the base-eliminated one (ik4.hip)
     wcqp_kin_t kin = nullptr;     // use_kinematics: Jacobians, actual poses and hull rows are rebuilt every tick
     KinTick kt{};
-    bool primed = false;          // skewed tick: MPC(ticks_enqueued) has run (the fused launch of tick t carries IK(t) and MPC(t+1))
     int phase = 0;                // which copy of the tick index the next launch reads (TickDev::tick2): toggles per LAUNCH
     int ticks_per_launch = 1;     // > 1: the fused kernel walks through that many ticks per launch (no per-tick kinematics)
 };
@@ -90,7 +89,7 @@ int dev_alloc(wcqp_tick_s* h, T** out, size_t count) {
 
 // one launch sequence of n_inner ticks (n_inner > 1: the fused base-eliminated kernel without per-tick kinematics only) with
 // the given phase (which copy of the tick index it reads: see TickDev::tick2)
-int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s, int n_inner = 1) {
+int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s, int n_inner = 1, int skip_last_mpc = 0) {
     TickDev d = h->d;
     d.phase = phase & 1;
     const int B = d.batch;
@@ -104,7 +103,7 @@ int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s, int n_inner = 1) {
     // base-eliminated IK kernel: IK + post step of this tick and MPC + glue + plant of the NEXT one in ONE launch (skewed tick)
     if (h->fused && h->base_elim)
         return wcqp_ik::ik4_launch_tick(wcqp::ik_device_params(h->ik), d, h->d_dev, h->J_left, h->J_right, h->J_neck, h->J_com,
-                                        h->ik_lo, h->ik_up, n_inner, s);
+                                        h->ik_lo, h->ik_up, n_inner, skip_last_mpc, s);
     int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick2 + d.phase, d.u_prev,
                                d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, d.hull_sets, d.hull_sets > 1 ? d.sel : nullptr,
                                d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
@@ -239,18 +238,15 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     UP_(d.ref_traj, in->ref_traj, B * d.traj_len * 16);
     UP_(d.phase0, in->phase0, B * 4); UP_(d.swing_twist, in->swing_twist, B * 48);
     if (d.skew) {
-        // state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (= measured ZMP), p_star, v_star_prev, dcm, spare;
-        // parity-0 hand-off record: the plant state at the start of tick 0 (what a download before the first run reports)
-        std::vector<double> mst(B * 16, 0.0), hand(B * 10, 0.0);
+        // state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (= measured ZMP), p_star, v_star_prev, dcm, spare
+        std::vector<double> mst(B * 16, 0.0);
         for (size_t i = 0; i < B; ++i)
             for (int ax = 0; ax < 2; ++ax) {
                 double* r = &mst[(i * 2 + ax) * 8];
                 r[0] = in->com0[2 * i + ax]; r[2] = in->com0[2 * i + ax]; r[3] = in->u_init[2 * i + ax];
                 r[4] = in->com0[2 * i + ax]; r[6] = in->dcm0[2 * i + ax];
-                hand[i * 10 + 4 + ax] = in->com0[2 * i + ax]; hand[i * 10 + 6 + ax] = in->dcm0[2 * i + ax];
             }
         WCQP_HIP_TRY(hipMemcpy(d.mst, mst.data(), B * 16 * 8, hipMemcpyHostToDevice));
-        WCQP_HIP_TRY(hipMemcpy(d.hand, hand.data(), B * 10 * 8, hipMemcpyHostToDevice));
         WCQP_HIP_TRY(hipMemset(d.sel_built, 0xff, B * 4));           // -1: every robot builds / copies its live rows at tick 0
         WCQP_HIP_TRY(hipMemset(d.live_nc, 0, B * 4));
     }
@@ -290,7 +286,6 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     WCQP_HIP_TRY(hipMemset(h->ik_lo, 0, B * 4)); WCQP_HIP_TRY(hipMemset(h->ik_up, 0, B * 4));      // no previous active set at tick 0
     h->uploaded = true;
     h->ticks_enqueued = 0;
-    h->primed = false;
     h->phase = 0;
     return WCQP_OK;
 }
@@ -300,23 +295,25 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
     // the trajectories hold max_ticks + N + 1 stages per instance: a tick beyond that would read its neighbour's
     if ((long)h->ticks_enqueued + n_ticks > (long)h->p.max_ticks) return WCQP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (h->d.skew && !h->primed && n_ticks > 0) {
-        // the fused launch of tick t carries IK(t) and MPC(t+1): MPC(0) goes first, on its own
+    if (n_ticks == 0) return WCQP_OK;
+    int left = n_ticks;
+    if (h->d.skew) {
+        // the fused launch of tick t carries IK(t) and MPC(t+1): the MPC of the call's first tick goes first, on its own, and
+        // the call's LAST tick does not run the MPC of the tick after it - between calls nothing is ahead of anything
         const int rc = wcqp_ik::ik4_launch_tick_prime(h->d, h->ticks_enqueued, s);
         if (rc != WCQP_OK) return rc;
-        h->primed = true;
     }
-    int left = n_ticks;
     // the fused kernel walks through several ticks per launch (the waves need no per-tick synchronisation): no graph needed
     if (h->ticks_per_launch > 1) {
         while (left > 0) {
             const int k = left < h->ticks_per_launch ? left : h->ticks_per_launch;
-            const int rc = enqueue_tick(h, h->phase, s, k);
+            const int rc = enqueue_tick(h, h->phase, s, k, k == left ? 1 : 0);
             if (rc != WCQP_OK) return rc;
             h->phase ^= 1; h->ticks_enqueued += k; left -= k;
         }
         return WCQP_OK;
     }
+    if (h->d.skew) left -= 1;      // the last tick of the call is a plain launch of its own (below)
     // kGraphTicks ticks per graph (the tick index lives in HBM, so the graph is tick-invariant): one
     // hipGraphLaunch costs about as much as four plain launches.  The graph is captured with phases 0, 1, 0, ...
     // and therefore replayed only from phase 0; from phase 1 a plain tick goes first.
@@ -346,6 +343,24 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         for (; left >= kGraphTicks; left -= kGraphTicks, h->ticks_enqueued += kGraphTicks) WCQP_HIP_TRY(hipGraphLaunch(h->graph_exec, s));
     }
     while (left > 0) { const int rc = plain(); if (rc != WCQP_OK) return rc; }
+    if (h->d.skew) {
+        const int rc = enqueue_tick(h, h->phase, s, 1, 1);
+        if (rc != WCQP_OK) return rc;
+        h->phase ^= 1; ++h->ticks_enqueued;
+    }
+    return WCQP_OK;
+}
+
+int wcqp_tick_splice_reference(wcqp_tick_t h, int32_t from_tick, int32_t n_stages, const double* ref_tail, void* stream) {
+    if (!h || !h->uploaded || !ref_tail || n_stages < 1) return WCQP_E_INVALID;
+    const TickDev& d = h->d;
+    // stages the ticks already enqueued have consumed as their own reference DCM stay as they are; everything a later
+    // tick's window can see may change
+    if (from_tick < h->ticks_enqueued || (long)from_tick + n_stages > (long)d.traj_len) return WCQP_E_INVALID;
+    // strided copy: row i of the tail goes to stages [from_tick, from_tick + n_stages) of instance i, in stream order
+    // behind the ticks already enqueued (the trajectory pointer the kernels - and any captured graph - hold does not change)
+    WCQP_HIP_TRY(hipMemcpy2DAsync(const_cast<double*>(d.ref_traj) + (size_t)from_tick * 2, (size_t)d.traj_len * 16, ref_tail, (size_t)n_stages * 16,
+                                  (size_t)n_stages * 16, (size_t)d.batch, hipMemcpyHostToDevice, (hipStream_t)stream));
     return WCQP_OK;
 }
 
@@ -358,15 +373,14 @@ int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
     DN_(out->u0_log, d.u0_log, (size_t)d.log_ticks * B * 16); DN_(out->dq_log, d.dq_log, (size_t)d.log_ticks * B * kDof * 8);
     DN_(out->q_des, d.q_des, B * kDof * 8);
     if (d.skew) {
-        // the MPC chain is one tick ahead of the IK; the plant state at the start of tick n (= after n ticks) is what MPC(n)
-        // put into its hand-off record (parity n & 1) before it advanced the plant
+        // the state of the MPC chain lives in per-axis records (TickDev::mst): com at [2], dcm at [6]
         if (out->dcm || out->com) {
-            std::vector<double> hand(B * 10);
-            WCQP_HIP_TRY(hipMemcpy(hand.data(), d.hand + (size_t)(h->ticks_enqueued & 1) * B * 10, B * 10 * 8, hipMemcpyDeviceToHost));
+            std::vector<double> mst(B * 16);
+            WCQP_HIP_TRY(hipMemcpy(mst.data(), d.mst, B * 16 * 8, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < B; ++i)
                 for (int ax = 0; ax < 2; ++ax) {
-                    if (out->com) out->com[2 * i + ax] = hand[i * 10 + 4 + ax];
-                    if (out->dcm) out->dcm[2 * i + ax] = hand[i * 10 + 6 + ax];
+                    if (out->com) out->com[2 * i + ax] = mst[(i * 2 + ax) * 8 + 2];
+                    if (out->dcm) out->dcm[2 * i + ax] = mst[(i * 2 + ax) * 8 + 6];
                 }
         }
     } else {
