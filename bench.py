@@ -81,8 +81,9 @@ def main():
                          "instances (one more, nearly empty, launch), general = the general kernel only")
     ap.add_argument("--tick-tables", action="store_true", help="tick workload: constant uploaded Jacobians and precomputed hull tables "
                     "(round-1 form) instead of per-tick kinematics")
-    ap.add_argument("--tick-dense-handoff", action="store_true", help="tick workload with kinematics: four dense Jacobians between the kinematics and the "
-                    "solve kernel instead of the compact per-joint records (A/B; same results)")
+    ap.add_argument("--tick-kin-handoff", choices=["fused", "dense", "compact"], default="fused",
+                    help="tick workload with kinematics: fused = the solve kernel evaluates the kinematics itself (one launch per tick / many ticks "
+                         "per launch); dense / compact = a kinematics launch per tick handing over four dense Jacobians / per-joint records (A/B; same results)")
     ap.add_argument("--ticks-per-launch", type=int, default=0, help="tick workload without per-tick kinematics: ticks the fused kernel runs per launch (0 = the library's default, 1 = one launch per tick)")
     ap.add_argument("--tick-cold-ik", action="store_true", help="tick workload: no IK hot start (every tick walks the active set from the unconstrained optimum)")
     ap.add_argument("--step-graph", action="store_true", help="qp workload: replay ONE hipGraph that holds the timed steps as P parallel chains (one per "
@@ -591,11 +592,13 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     kin_mode = not args.tick_tables
     # the walking robots carry per-joint velocity limits (synth.WALK_VMAX: legs 1.5, torso and arms 0.3 rad/s - DESIGN.md 8.2)
     vmax = args.ik_vmax if args.tick_tables else wca.synth.WALK_VMAX
-    # `--streams 2`: the batch is cut into two independent halves, each its own pipeline on its own HIP stream.
-    # Synthetic robots are counter-based, so the two halves are exactly the rows of the full batch.
-    # robot groups, each a pipeline on a stream of its own: two halves with constant Jacobians, three thirds with the
-    # kinematics launch in the tick up to 16384 robots (-2 % per tick at 8192; four buy nothing more; at 65536 three cost 14 %)
-    n_streams = args.streams if args.streams else ((3 if (kin_mode and B <= 16384) else 2) if B >= 8192 else 1)
+    # Robot groups, each a pipeline on a HIP stream of its own (synthetic robots are counter-based, so the groups are exactly
+    # the rows of the full batch).  When a tick is ONE launch of the fused kernel (constant Jacobians, or kinematics fused
+    # in) the library runs all the ticks of a run() call in one launch and one group is best (three concurrent launches of a
+    # third of the robots each: 5.2e8 against 7.7e8 QP/s with kinematics at 8192 robots).  With a kinematics launch per tick
+    # (--tick-kin-handoff dense / compact) or one tick per launch, groups overlap one group's kernel with another's.
+    multi_tick = args.ticks_per_launch != 1 and (not kin_mode or args.tick_kin_handoff == "fused")
+    n_streams = args.streams if args.streams else (1 if multi_tick else ((3 if (kin_mode and B <= 16384) else 2) if B >= 8192 else 1))
     cuts = [B * k // n_streams for k in range(n_streams + 1)]
     parts = [(first + cuts[k], cuts[k + 1] - cuts[k]) for k in range(n_streams)]
     ik_form = wca.IK_FORM_QPOASES if args.ik_form == "qpoases" else wca.IK_FORM_OSQP
@@ -611,7 +614,7 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
             data = wca.synth.synth_tick_batch(cnt, T, first=f0)
             iks = wca.IkSolver(form=ik_form, v_max=vmax)
         pp = wca.TickPipeline(cnt, T, wca.MpcSolver(horizon=50), iks, first=f0, kin=kin, ik_hot_start=not args.tick_cold_ik,
-                              kin_dense_handoff=args.tick_dense_handoff, ticks_per_launch=args.ticks_per_launch)
+                              kin_handoff={"fused": 0, "dense": 1, "compact": 2}[args.tick_kin_handoff], ticks_per_launch=args.ticks_per_launch)
         pp.upload(data)
         pipes.append(pp)
     stream = torch.cuda.current_stream(dev)
@@ -651,11 +654,25 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
     stopped_ticks = int(np.maximum(out_state["ik_fail"] - 1, 0).sum())
     stopped_ticks_all = int(round(sum_over_ranks(dist, torch, dev, float(stopped_ticks))))
     value = (2 * B * world * args.steps - stopped_ticks_all) / elapsed
-    # algorithmic I/O of a tick (6296 B) + resident controller / plant state read and written; with per-tick
-    # kinematics the Jacobians and actual poses are written by one kernel and read by the next (4464 B more)
-    bytes_per_tick = 6296 + 2 * 8 * (2 * 10 + 23 * 3) + (4464 + 280 if kin_mode else 0)
-    launches = ("2 launches: kin_jacobians_kernel<TICK>, ik4_kernel<TICK> with MPC, glue, IK and post step fused" if kin_mode
-                else "1 launch: ik4_kernel<TICK> with MPC, glue, IK and post step fused")
+    # Roofline of the tick, two denominators:
+    #  `frac`      SURVEY.md 8d's algorithmic bytes of a robot-tick, 6296 B (one cold-start MPC + one IK with four dense Jacobians
+    #              in, u0 + dq out) - what any implementation of the two QPs has to be given and has to return;
+    #  `frac_own`  the bytes THIS pipeline moves through HBM per robot-tick: the IK's pose block and joint state, the MPC's
+    #              window (one new stage per tick, the rest re-read from L2), resident controller / plant state read + written,
+    #              logs; with constant Jacobians the 4464 B of Jacobians every tick; with a kinematics launch per tick its
+    #              hand-off written and read (dense 4464 + 4464, compact 1440 + 1440); with fused kinematics no Jacobian bytes at all.
+    state_rw = 2 * 8 * (16 + 10 + 23 * 2) + 87 * 8 + 23 * 8 + 16 + 8       # mst + hand + q_des/dq_prev r/w, pose block, dq out, one reference stage, words
+    jac_bytes = 4464 if not kin_mode else {"fused": 0, "compact": 2 * 1440 + 288, "dense": 2 * 4464 + 288}[args.tick_kin_handoff]
+    own_bytes = state_rw + jac_bytes
+    bytes_per_tick = 6296
+    if kin_mode:
+        launches = {"fused": "1 launch per run() call: ik4_kernel<TICK, fused kinematics> walks through the ticks (kinematics, MPC of the next tick, glue, IK, post step)",
+                    "compact": "2 launches per tick: kin_jacobians_kernel<TICK, compact>, ik4_kernel<TICK>",
+                    "dense": "2 launches per tick: kin_jacobians_kernel<TICK>, ik4_kernel<TICK>"}[args.tick_kin_handoff]
+    else:
+        launches = "1 launch per run() call: ik4_kernel<TICK> walks through the ticks (MPC of the next tick, glue, IK, post step)"
+    if args.ticks_per_launch == 1:
+        launches = launches.replace("1 launch per run() call", "1 launch per tick (hipGraph of 8)").replace("walks through the ticks", "")
     out = {
         "metric": METRIC, "value": value, "unit": "QP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -671,7 +688,9 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
         },
         "roofline": {"bound": "hbm", "kernel": "whole tick (%s)" % launches, "achieved": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_tick * B / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "avg_launch_ms": dev_ms, "algorithmic_bytes_per_launch": bytes_per_tick * B},
+                     "traffic": None, "avg_launch_ms": dev_ms, "algorithmic_bytes_per_launch": bytes_per_tick * B,
+                     "algorithmic_bytes_basis": "SURVEY.md 8d: 6296 B per robot-tick (1056 MPC + 5240 IK), per TICK (a launch runs many)",
+                     "own_hbm_bytes_per_robot_tick": own_bytes, "frac_own": own_bytes * B / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "solved": {"ticks_executed": out_state["tick"], "mpc_fail": int(out_state["mpc_fail"].sum()),
                    "ik_fail": int(out_state["ik_fail"].sum()), "robots_with_ik_fail": int((out_state["ik_fail"] > 0).sum()), "of": B * T,
                    "stopped_robot_ticks_not_counted": stopped_ticks_all,

@@ -350,6 +350,9 @@ int wcqp_kin_jacobians_host(wcqp_kin_t h, int32_t batch, const double* base, con
  * algorithm or the CoM-as-cost variant four (stand-alone glue / post kernels).  `use_graph` replays hipGraphs of 8 ticks each (captured
  * ONCE: the tick index lives in device memory), remaining ticks go as plain launches.
  * ===================================================================================== */
+#define WCQP_KIN_HANDOFF_FUSED   0
+#define WCQP_KIN_HANDOFF_DENSE   1
+#define WCQP_KIN_HANDOFF_COMPACT 2
 typedef struct wcqp_tick_params {
     int32_t batch;              /* instances on this device                                   */
     int32_t first;              /* global index of instance 0 (disturbance stream)             */
@@ -377,14 +380,19 @@ typedef struct wcqp_tick_params {
     int32_t use_kinematics;
     wcqp_kin_params kin;
     double  foot_rect[8];       /* corners (x, y) x 4 of the foot rectangle in the foot frame (foot_size, cpp:295-303) */
-    /* Per-tick kinematics hand the IK of the same tick its Jacobians through device memory.  By default (0) that hand-off
-     * is COMPACT whenever every joint lies on the path of at most one of the three frames (left sole, right sole, neck - true
-     * of a humanoid whose legs and torso branch at the root link): per joint its CoM column and its column of that ONE frame
-     * Jacobian, plus the three vectors p_frame - p_base that make up the base blocks [I -S(p); 0 I] - 1.4 KB per robot
-     * instead of the 4.4 KB of four dense Jacobians, ~70 % of which are structural zeros.  1 = dense Jacobians (the layouts
-     * of wcqp_kin_jacobians_* / wcqp_ik_solve_*); same results. */
-    int32_t kin_dense_handoff;
-    /* Ticks per launch of the fused kernel (default IK kernel, no per-tick kinematics): the robots of a wavefront depend on
+    /* How the per-tick kinematics reach the IK of the same tick (WCQP_KIN_HANDOFF_*; same results):
+     * FUSED (0, default)  no hand-off at all: the wavefront that solves a robot's IK first evaluates its forward kinematics and
+     *           its Jacobian columns (16 lanes per robot, two joints per lane) - one launch per tick, or many ticks per launch
+     *           (ticks_per_launch).  Needs a tree whose joints each lie on the path of at most ONE of the three frames (left sole,
+     *           right sole, neck: a humanoid whose legs and torso branch at the root link), depth-first joint numbering, depth
+     *           <= 8 and an MPC horizon <= 63; otherwise COMPACT is taken.
+     * DENSE (1)   a kinematics launch per tick writes the four dense Jacobians (the layouts of wcqp_kin_jacobians_* /
+     *           wcqp_ik_solve_*), 4.4 KB per robot of which ~70 % are structural zeros.
+     * COMPACT (2) a kinematics launch per tick writes, per joint, its CoM column and its column of the ONE frame Jacobian
+     *           it is on the path of, plus the three vectors p_frame - p_base that make up the base blocks [I -S(p); 0 I]:
+     *           1.4 KB per robot (same condition on the tree as FUSED, else DENSE). */
+    int32_t kin_handoff;
+    /* Ticks per launch of the fused kernel (default IK kernel; constant Jacobians or FUSED kinematics): the robots of a wavefront depend on
      * no other wavefront's, so a wave walks through the ticks of a wcqp_tick_run call on its own - no launch, ramp-up or tail
      * per tick, and a wave whose robots walk a long active set falls behind without holding anybody up.
      * 0 -> all the ticks of a wcqp_tick_run call in one launch; k > 0: at most k per launch; 1 = one launch per tick (what

@@ -177,7 +177,7 @@ def _walk_scenario(wca, B, T, first=0):
     return kin, wca.synth.synth_walk_batch(B, T, poses, kb, first=first)
 
 
-def _kin_tick_against_oracle(wca, qs, B, T, vmax, ik_algorithm, dense_handoff=False, graphs=(False, True)):
+def _kin_tick_against_oracle(wca, qs, B, T, vmax, ik_algorithm, handoff=0, graphs=(False, True), ticks_per_launch=0):
     from oracle import tick_spec as ts
     p = ts.TickParams()
     kin, d = _walk_scenario(wca, B, T)
@@ -189,7 +189,7 @@ def _kin_tick_against_oracle(wca, qs, B, T, vmax, ik_algorithm, dense_handoff=Fa
     outs = []
     for use_graph in graphs:
         ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm, joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
-        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik, log_ticks=T, kin=kin, kin_dense_handoff=dense_handoff)
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik, log_ticks=T, kin=kin, kin_handoff=handoff, ticks_per_launch=ticks_per_launch)
         pipe.upload(d)
         pipe.run(T, use_graph=use_graph)
         out = pipe.download()
@@ -204,16 +204,19 @@ def _kin_tick_against_oracle(wca, qs, B, T, vmax, ik_algorithm, dense_handoff=Fa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["kin+fused_solve", "kin+fused_solve,dense_handoff", "kin+mpc+ik"])
+@pytest.mark.parametrize("variant", ["fused_kinematics", "fused_kinematics,one_tick_per_launch", "kin_launch+compact_handoff", "kin_launch+dense_handoff", "kin+mpc+ik"])
 def test_tick_pipeline_with_per_tick_kinematics_matches_cpu_restatement(wca, qs, variant):
     """SURVEY 8f-4 inside the tick: every tick evaluates the forward kinematics at the integrated joint state with the base
     anchored at the stance foot and hands fresh MIXED Jacobians and the actual poses to the IK
-    (WM/src/WalkingModule.cpp:715, 396-410) - as the compact per-joint records of the tick's own hand-off (default), as four
-    dense Jacobians (`kin_dense_handoff`), or through the general 16-lane kernel with a stand-alone MPC launch (algorithm 4);
+    (WM/src/WalkingModule.cpp:715, 396-410) - inside the solve kernel itself (default; many ticks per launch or one), through a
+    kinematics launch per tick that hands over compact per-joint records or four dense Jacobians (`kin_handoff`), or through the
+    general 16-lane kernel with a stand-alone MPC launch (algorithm 4);
     the support polygons come from the desired foot poses (...PredictiveController.cpp:364-435).  150 closed-loop ticks against
     oracle/tick_spec.py (kin_spec + hull_spec + the exact QP solvers) at 1e-9, graph replay == plain launches bitwise, no robot fails."""
     alg = 4 if variant == "kin+mpc+ik" else 0
-    d, ref, (eager, out), vmax = _kin_tick_against_oracle(wca, qs, 12, 150, wca.synth.WALK_VMAX, alg, dense_handoff="dense" in variant)
+    handoff = wca.KIN_HANDOFF_DENSE if "dense" in variant else (wca.KIN_HANDOFF_COMPACT if "compact" in variant else wca.KIN_HANDOFF_FUSED)
+    d, ref, (eager, out), vmax = _kin_tick_against_oracle(wca, qs, 12, 150, wca.synth.WALK_VMAX, alg, handoff=handoff,
+                                                          ticks_per_launch=1 if "one_tick" in variant else 0)
     assert ref["ik_fail"].sum() == 0                       # the walk scenario does not fall (DESIGN.md 8.2)
     assert np.abs(ref["q_des"] - d["q0"]).max() > 0.05     # the Jacobians really change: the joints travel
     assert np.array_equal(out["u0_log"], eager["u0_log"]) and np.array_equal(out["dq_log"], eager["dq_log"])   # graph == eager, bitwise
@@ -221,21 +224,23 @@ def test_tick_pipeline_with_per_tick_kinematics_matches_cpu_restatement(wca, qs,
 
 
 @pytest.mark.gpu
-def test_compact_and_dense_kinematics_handoff_agree(wca):
-    """The compact kinematics -> IK hand-off carries exactly the non-zero entries of the four Jacobians: both forms of the
-    tick give the same trajectories (the IK sees the same numbers; only exact zeros differ in how they are formed)."""
+def test_kinematics_handoff_forms_agree(wca):
+    """The compact kinematics -> IK hand-off carries exactly the non-zero entries of the four Jacobians, and the fused kinematics
+    phase computes them where they are used: all three forms of the tick give the same trajectories (the kinematics kernel's
+    two forms bit for bit in u0; the fused phase, 16 lanes per robot instead of 32, to rounding)."""
     B, T = 256, 64
     kin, d = _walk_scenario(wca, B, T)
     res = []
-    for dense in (False, True):
+    for handoff in (wca.KIN_HANDOFF_COMPACT, wca.KIN_HANDOFF_DENSE, wca.KIN_HANDOFF_FUSED):
         ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=wca.synth.WALK_VMAX, joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
-        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik, log_ticks=T, kin=kin, kin_dense_handoff=dense)
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik, log_ticks=T, kin=kin, kin_handoff=handoff)
         pipe.upload(d); pipe.run(T, use_graph=True)
         res.append(pipe.download())
-    a, b = res
-    assert a["ik_fail"].sum() == 0 and b["ik_fail"].sum() == 0
-    assert np.array_equal(a["u0_log"], b["u0_log"])
+    a, b, c = res
+    assert a["ik_fail"].sum() == 0 and b["ik_fail"].sum() == 0 and c["ik_fail"].sum() == 0
+    assert np.array_equal(a["u0_log"], b["u0_log"]) and np.array_equal(a["u0_log"], c["u0_log"])
     assert np.abs(a["dq_log"] - b["dq_log"]).max() <= 1e-12 and np.abs(a["q_des"] - b["q_des"]).max() <= 1e-12
+    assert np.abs(a["dq_log"] - c["dq_log"]).max() <= 1e-10 and np.abs(a["q_des"] - c["q_des"]).max() <= 1e-11
 
 
 @pytest.mark.gpu

@@ -22,6 +22,7 @@ STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_OUTSIDE_HULL, STATUS_N
 IK_FORM_QPOASES, IK_FORM_OSQP = 0, 1
 IK_ALG_DEFAULT, IK_ALG_SWEEP, IK_ALG_NULLSPACE, IK_ALG_NULLSPACE_MFMA, IK_ALG_NULLSPACE_16L, IK_ALG_BASE_ELIM = 0, 1, 2, 3, 4, 5
 IK_JAC_AUTO, IK_JAC_MIXED, IK_JAC_GENERAL = 0, 1, 2
+KIN_HANDOFF_FUSED, KIN_HANDOFF_DENSE, KIN_HANDOFF_COMPACT = 0, 1, 2
 HULL_ROWS = 8
 MAX_DOF = 32
 IK_STATE_LEN = 87
@@ -97,7 +98,7 @@ class TickParams(C.Structure):
                 ("k_com", C.c_double), ("k_zmp", C.c_double), ("noise", C.c_double), ("seed", C.c_uint64),
                 ("mpc", MpcParams), ("ik", IkParams),
                 ("ik_cold_start_only", C.c_int32), ("use_kinematics", C.c_int32), ("kin", KinParams), ("foot_rect", C.c_double * 8),
-                ("kin_dense_handoff", C.c_int32), ("ticks_per_launch", C.c_int32)]
+                ("kin_handoff", C.c_int32), ("ticks_per_launch", C.c_int32)]
 
 
 class TickInputs(C.Structure):
@@ -363,7 +364,7 @@ class TickPipeline:
 
     def __init__(self, batch, max_ticks, mpc: MpcSolver, ik: IkSolver, first=0, log_ticks=0,
                  step_ticks=180, ds_ticks=110, k_com=9.0, k_zmp=3.0, noise=1e-4, seed=99,
-                 kin: "Optional[KinModel]" = None, foot_rect=None, ik_hot_start: bool = True, kin_dense_handoff: bool = False,
+                 kin: "Optional[KinModel]" = None, foot_rect=None, ik_hot_start: bool = True, kin_handoff: int = 0,
                  ticks_per_launch: int = 0):
         """kin: a KinModel -> per-tick kinematics (Jacobians, actual poses and hull rows rebuilt every tick from the
         integrated joint state with the base anchored at the stance foot; upload() then ignores J_* / hull_tab_*)."""
@@ -374,7 +375,7 @@ class TickPipeline:
             foot_rect = FOOT_RECT
         self.params = TickParams(batch, first, max_ticks, log_ticks, step_ticks, ds_ticks, k_com, k_zmp, noise, seed,
                                  mpc.params, ik.params, int(not ik_hot_start), int(self.use_kin), kin.params if kin is not None else KinParams(),
-                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(bool(kin_dense_handoff)), int(ticks_per_launch))
+                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(kin_handoff), int(ticks_per_launch))
         self._h = C.c_void_p()
         check(lib().wcqp_tick_create(C.byref(self.params), C.byref(self._h)), "wcqp_tick_create")
         self._keep = None

@@ -38,6 +38,7 @@
 #include <type_traits>
 #include "ik_common.h"
 #include "tick_device.h"
+#include "kin_device.h"
 
 namespace {
 
@@ -109,7 +110,9 @@ __device__ __forceinline__ void swap16(double& a, double& b) {
 __device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 
-template <bool TICK, bool COMPACT = false>
+// JSRC: where the Jacobians come from - 0 the four dense arrays of the ABI, 1 the compact per-joint records of the tick's
+// kinematics kernel (tick_device.h), 2 the kinematics phase of this kernel itself (no hand-off through memory at all)
+template <bool TICK, int JSRC = 0>
 __device__ __forceinline__
 void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -118,8 +121,10 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev& td, double (*smem)[PER_INST], int blk,
-                const int tick_now = 0, const bool do_mpc = true)
+                const int tick_now = 0, const bool do_mpc = true, const double* kmodel = nullptr, const double* gr_lds = nullptr)
 {
+    constexpr bool COMPACT = JSRC == 1;
+    constexpr bool KINF = JSRC == 2;
     int lane_id = threadIdx.x;
     // inside the tick kernel's loop over ticks: keeps hipcc from hoisting every per-lane address and constant of the body
     // out of the loop (they would all be live across the whole body: +100 VGPRs and spills)
@@ -140,17 +145,24 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 
     unsigned prev_lo = 0u, prev_up = 0u;            // hot start: the previous tick's active bounds of this instance
     bool stopped = false;                           // tick pipeline: the robot's IK failed on an earlier tick (tick_device.h)
-    if constexpr (TICK) {
+    auto load_previous_set = [&]() {
         if (td.hot_start && alo_out && aup_out) { prev_lo = alo_out[inst]; prev_up = aup_out[inst]; }
         stopped = wcqp_tick::tick_robot_stopped(td, (int)inst);
         if (stopped) { prev_lo = 0u; prev_up = 0u; }
-    }
+    };
+    if constexpr (TICK && JSRC != 2) load_previous_set();
 
     WCQP_STAMP(0);
     // ---------------- phase 0: loads ------------------------------------------------------------
     const int v0i = 6 + j, v1i = var1 ? 22 + j : 0;           // index into the per-variable constant tables
-    const double sd0 = prm->sd[j], sd1 = prm->sd[col1], isd0 = prm->isd[j], isd1 = prm->isd[col1];
-    const double kq0 = prm->kq[v0i], kq1 = prm->kq[v1i], qreg0 = prm->qreg[v0i], qreg1 = prm->qreg[v1i];
+    // per-lane constants: up front, in the shadow of the input loads - or (fused kinematics) behind the kinematics phase,
+    // in the shadow of the MPC arithmetic: across that phase every register counts
+    double sd0, sd1, isd0, isd1, kq0, kq1, qreg0, qreg1;
+    auto load_lane_constants = [&]() {
+        sd0 = prm->sd[j]; sd1 = prm->sd[col1]; isd0 = prm->isd[j]; isd1 = prm->isd[col1];
+        kq0 = prm->kq[v0i]; kq1 = prm->kq[v1i]; qreg0 = prm->qreg[v0i]; qreg1 = prm->qreg[v1i];
+    };
+    if constexpr (!KINF) load_lane_constants();
     double a0[NROWS_IN], a1[NROWS_IN];     // columns of [J_left; J_right; J_com; J_neck]
     double q0, q1;
     bool osqp_form;
@@ -161,32 +173,305 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     // behind them, and its arithmetic runs while the Jacobians are in flight; IK(t) reads what MPC(t) left in the hand-off
     // record one launch ago (the first launch after an upload is primed by tick_mpc_prime_kernel, tick.hip).
     wcqp_tick::TickMpcRegs mreg;
-    if constexpr (TICK) { if (do_mpc) wcqp_tick::tick_mpc_issue(td, j, inst, tick_now + 1, mreg); else mreg.phase0 = td.phase0[inst]; }
+    if constexpr (TICK) { if (do_mpc) wcqp_tick::tick_mpc_issue<KINF>(td, j, inst, tick_now + 1, mreg); else mreg.phase0 = td.phase0[inst]; }
     double2 cr0[5], cr1[5], cdv[5];        // COMPACT: the two joint records and the three vectors p_frame - p_base, as loaded
     int ckind0 = 0, ckind1 = 0;
+    double m_ux = 0.0, m_uy = 0.0;         // ... the MPC chain's partial sums, reduced early
+    double2 m_r0 = make_double2(0.0, 0.0);
     {
         // the state block first: vmcnt retires in order, and the rhs phase only needs the state, so the 36
         // Jacobian loads stay in flight underneath it
         const double* sp = state + inst * kStateLen;
         double sreg[6];
+        if constexpr (!KINF) {
 #pragma unroll
-        for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
-        sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
+            for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
+            sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
+        }
         q0 = qpos[inst * kDof + j];
         q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
         double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0, g_ok = 1.0, g_sw = 0.0, g_h0 = 0.0;
-        if constexpr (TICK) {
+        auto load_handoff = [&]() {
             // hand-off of MPC(t): desired CoM position / velocity (WalkingModule.cpp:686-695), the plant's CoM, did the MPC end usable
             const double* hd = td.hand + ((size_t)(tick_now & 1) * td.batch + inst) * 10;
             const int ja = j & 1;
             g_pstar = hd[ja]; g_vel = hd[2 + ja]; g_com = hd[4 + ja]; g_ok = hd[8];
             g_sw = td.swing_twist[inst * 6 + (j < 6 ? j : 0)];
             g_h0 = td.kin_mode ? td.com_h0[inst] : td.com_height;
-        }
+        };
+        if constexpr (TICK && !KINF) load_handoff();
         // the state / q loads above must ISSUE before the 36 column loads (vmcnt retires in order): hipcc otherwise sinks
         // one of them below the Jacobian loads and the state's LDS stores then wait for everything (vmcnt(0))
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (COMPACT) {
+        if constexpr (KINF) {
+            // ================= kinematics phase (wcqp_tick_params.use_kinematics, fused): forward kinematics at the integrated
+            // joint state with the base anchored at the stance foot (WalkingFK::evaluateWorldToBaseTransformation,
+            // WM/src/WalkingForwardKinematics.cpp:160-256; WM/src/WalkingModule.cpp:715, 396-410) and this lane's two columns of
+            // the four MIXED Jacobians, straight into the registers the row operations read.  Same algebra as
+            // kin_jacobians_kernel (kin.hip), laid out for the IK's 16 lanes per robot: lane j owns joints j and 16 + j.
+            using namespace wcqp_kin;
+            constexpr int K_TW = 0, K_FRB = 276, K_FR = 312;     // joint frames [23][12], attached frames (base / world) [3][12] each
+            static_assert(K_FR + 36 <= PER_INST && kDof * 12 <= K_FRB, "kinematics scratch fits the instance's LDS");
+            constexpr int K_MS = 348, K_MH = 364, K_SD = 388;      // stashes (the sweep's region B is idle): MPC per-axis records [2][8], MPC hull rows [8][3], anchor pose [12]
+            static_assert(K_SD + 12 <= PER_INST, "stashes fit");
+            // every register counts across this phase: what the MPC chain of tick t + 1 has loaded is reduced to this lane's share
+            // of u0_unc now (its loads were issued first: they have landed when the pose block below has) and its per-axis records
+            // and hull row wait in LDS; the pose block is re-read behind the kinematics (L2) instead of being held
+            if (do_mpc) {
+                wcqp_tick::tick_mpc_partial<true>(td, j, inst, tick_now + 1, mreg, gr_lds, m_ux, m_uy);
+                m_r0 = mreg.L.r[0];
+                if (j < 2) {
+                    double* ms = S + K_MS + j * 8;
+                    st2(ms, mreg.s01.x, mreg.s01.y); st2(ms + 2, mreg.s23.x, mreg.s23.y); st2(ms + 4, mreg.s45.x, mreg.s45.y); st2(ms + 6, mreg.s67.x, mreg.s67.y);
+                }
+                if (j < 8) { double* mh = S + K_MH + j * 3; mh[0] = mreg.ha.x; mh[1] = mreg.ha.y; mh[2] = mreg.hb; }
+            }
+            {
+                const int side_ = ((tick_now + mreg.phase0) % (2 * td.step_ticks)) / td.step_ticks;     // 0: left is the stance foot
+                if (j < 12) S[K_SD + j] = state[inst * kStateLen + 24 + side_ * 12 + j];                // desired pose of the anchor sole: p (3), R (9)
+            }
+            const int side = ((tick_now + mreg.phase0) % (2 * td.step_ticks)) / td.step_ticks;
+            const int cs[2] = {j, var1 ? col1 : 0};
+            double* TW = S + K_TW;
+            {
+            double Ra[2][9], pa[2][3];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const double* mt = kmodel + cs[s_] * wcqp_tick::kKinTabJoint;
+                double R0[9], axl[3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R0[k] = mt[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { pa[s_][k] = mt[9 + k]; axl[k] = mt[12 + k]; }
+                joint_rotation(R0, axl, s_ == 0 ? q0 : q1, Ra[s_]);
+            }
+            // the tree in base coordinates by pointer jumping (kin.hip): after round r a frame is relative to its 2^(r+1)-th ancestor
+#pragma unroll 1
+            for (int r = 0; r < td.kin_rounds; ++r) {
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    if (s_ == 0 || var1) {
+                        double* Tm = TW + cs[s_] * 12;
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2) st2(Tm + k, Ra[s_][k], Ra[s_][k + 1]);
+                        st2(Tm + 8, Ra[s_][8], pa[s_][0]); st2(Tm + 10, pa[s_][1], pa[s_][2]);
+                    }
+                }
+                wcqp::wave_lds_fence();
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    const int u = td.kin_up[r][cs[s_]];
+                    if (u >= 0 && (s_ == 0 || var1)) {
+                        const double* T = TW + u * 12;
+                        double Rp[9], pp[3], Rn[9], pn[3];
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Rp[k] = T[k];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) pp[k] = T[9 + k];
+                        frame_mul(Rp, pp, Ra[s_], pa[s_], Rn, pn);
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Ra[s_][k] = Rn[k];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) pa[s_][k] = pn[k];
+                    }
+                }
+                wcqp::wave_lds_fence();
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                if (s_ == 0 || var1) {
+                    double* Tm = TW + cs[s_] * 12;
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) st2(Tm + k, Ra[s_][k], Ra[s_][k + 1]);
+                    st2(Tm + 8, Ra[s_][8], pa[s_][0]); st2(Tm + 10, pa[s_][1], pa[s_][2]);
+                }
+            }
+            }
+            wcqp::wave_lds_fence();
+            // attached frames (left sole, right sole, neck) in base coordinates: lanes 0..2
+            const int fi = j < 3 ? j : 0;
+            double Rf[9], pf[3];
+            {
+                const double* T = TW + td.kin_frame_joint[fi] * 12;
+                const double* ft = kmodel + wcqp_tick::kKinTabFrames + fi * 12;
+                double Rj[9], pj[3], fR[9], fp[3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { Rj[k] = T[k]; fR[k] = ft[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { pj[k] = T[9 + k]; fp[k] = ft[9 + k]; }
+                frame_mul(Rj, pj, fR, fp, Rf, pf);
+                if (j < 3) {
+                    double* F = S + K_FRB + j * 12;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) F[k] = Rf[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) F[9 + k] = pf[k];
+                }
+            }
+            wcqp::wave_lds_fence();
+            // base pose from the anchor foot: world_T_base = world_T_sole,desired * (base_T_sole)^-1
+            double pb[3], Rb[9];
+            {
+                const double* Fs = S + K_FRB + side * 12;
+                double Rs[9], ps[3], d3[3], sdp[3], sdR[9];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) sdp[k] = S[K_SD + k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sdR[k] = S[K_SD + 3 + k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Rs[k] = Fs[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ps[k] = Fs[9 + k];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Rb[3 * r + c] = sdR[3 * r] * Rs[3 * c] + sdR[3 * r + 1] * Rs[3 * c + 1] + sdR[3 * r + 2] * Rs[3 * c + 2];
+                mat3_vec(Rb, ps, d3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pb[k] = sdp[k] - d3[k];
+            }
+            // attached frames in world coordinates
+            if (j < 3) {
+                double Rg[9], pg[3];
+                frame_mul(Rb, pb, Rf, pf, Rg, pg);
+                double* F = S + K_FR + j * 12;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) F[k] = Rg[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) F[9 + k] = pg[k];
+            }
+            // own joints in world coordinates, their axes, link first moments {m c, m}
+            double pw[2][3], aw[2][3], e4[2][4];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const double* mt = kmodel + cs[s_] * wcqp_tick::kKinTabJoint;
+                double Rw[9], cl[3], Rl[9], pl[3];
+                {   // the joint's frame in base coordinates, back from LDS (not held in registers across the frames / base pose above)
+                    const double* Tm = TW + cs[s_] * 12;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Rl[k] = Tm[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) pl[k] = Tm[9 + k];
+                }
+                frame_mul(Rb, pb, Rl, pl, Rw, pw[s_]);
+                const double axl[3] = {mt[12], mt[13], mt[14]};
+                mat3_vec(Rw, axl, aw[s_]);
+                const double cj[3] = {mt[15], mt[16], mt[17]};
+                const double mj = (s_ == 0 || var1) ? mt[18] : 0.0;
+                mat3_vec(Rw, cj, cl);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) e4[s_][k] = mj * (pw[s_][k] + cl[k]);
+                e4[s_][3] = mj;
+            }
+            wcqp::wave_lds_fence();          // FR is complete; the joint frames are dead: the prefix sums overlay them
+            // ---- frame columns: joint c is on the path of at most one of the three frames (compact_offset: kind)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                int kind;
+                (void)wcqp_tick::compact_offset(td.cmaskL, td.cmaskR, td.cmaskN, cs[s_], kind);
+                if (s_ == 1 && !var1) kind = 0;
+                const double* F = S + K_FR + (kind > 0 ? kind - 1 : 0) * 12;
+                const double d3[3] = {F[9] - pw[s_][0], F[10] - pw[s_][1], F[11] - pw[s_][2]};
+                double lin[3];
+                cross3(aw[s_], d3, lin);
+                const double mL = kind == 1 ? 1.0 : 0.0, mR = kind == 2 ? 1.0 : 0.0, mN = kind == 3 ? 1.0 : 0.0;
+                double (&a)[NROWS_IN] = s_ == 0 ? a0 : a1;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    a[r] = mL * lin[r]; a[3 + r] = mL * aw[s_][r];
+                    a[6 + r] = mR * lin[r]; a[9 + r] = mR * aw[s_][r];
+                    a[15 + r] = mN * aw[s_][r];
+                }
+            }
+            // ---- subtree first moments: the joint numbering is depth-first, a subtree is an index range; inclusive prefix sums
+            // over joints 0..15 (slot 0, a DPP row scan) and 16.. (slot 1, offset by the row's total)
+            double* PS = S + K_TW;               // [32][4]
+            {
+                double p0s[4], p1s[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { p0s[k] = row_scan(e4[0][k]); p1s[k] = row_scan(e4[1][k]); }
+                st2(PS + j * 4, p0s[0], p0s[1]); st2(PS + j * 4 + 2, p0s[2], p0s[3]);
+                wcqp::wave_lds_fence();
+                const double2 t01 = ld2(PS + 15 * 4), t23 = ld2(PS + 15 * 4 + 2);
+                st2(PS + (16 + j) * 4, p1s[0] + t01.x, p1s[1] + t01.y); st2(PS + (16 + j) * 4 + 2, p1s[2] + t23.x, p1s[3] + t23.y);
+                wcqp::wave_lds_fence();
+            }
+            double tot[4], ctot[3];
+            {
+                const double* rt = kmodel + wcqp_tick::kKinTabRoot;
+                const double rootc[3] = {rt[0], rt[1], rt[2]};
+                const double root_mass = rt[3];
+                double cr[3];
+                mat3_vec(Rb, rootc, cr);
+                const double* Pt = PS + (kDof - 1) * 4;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) tot[k] = Pt[k] + root_mass * (pb[k] + cr[k]);
+                tot[3] = Pt[3] + root_mass;
+            }
+            const double iM = 1.0 / tot[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ctot[k] = tot[k] * iM;
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const int c = cs[s_];
+                const double* Pe = PS + td.kin_sub_end[c] * 4;
+                const double* Pb = PS + (c > 0 ? c - 1 : 0) * 4;
+                const double z = c > 0 ? 1.0 : 0.0;
+                const double ms = Pe[3] - z * Pb[3];
+                const double d3[3] = {(Pe[0] - z * Pb[0] - ms * pw[s_][0]) * iM, (Pe[1] - z * Pb[1] - ms * pw[s_][1]) * iM, (Pe[2] - z * Pb[2] - ms * pw[s_][2]) * iM};
+                double lin[3];
+                cross3(aw[s_], d3, lin);
+                double (&a)[NROWS_IN] = s_ == 0 ? a0 : a1;
+                const double mv = (s_ == 0 || var1) ? 1.0 : 0.0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) a[12 + r] = mv * lin[r];
+            }
+            // the vectors the base blocks [I -S(p); 0 I] are made of: p_left - p_base, p_right - p_base, p_com - p_base
+            double kdv[9];
+            {
+                const double* FL = S + K_FR, *FRt = S + K_FR + 12;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { kdv[k] = FL[9 + k] - pb[k]; kdv[3 + k] = FRt[9 + k] - pb[k]; kdv[6 + k] = ctot[k] - pb[k]; }
+            }
+            // (the attached frames in world coordinates stay in LDS - they are the ACTUAL poses the pose block gets below - and the
+            // CoM joins them in the anchor pose's stash, which is dead)
+            wcqp::wave_lds_fence();
+            if (j < 3) S[K_SD + j] = ctot[j];
+            // (pinned: hipcc otherwise hoists these loads - 44 registers of results - to the top of the kinematics phase)
+            __builtin_amdgcn_sched_barrier(0);
+            // the pose block, the per-lane constants and the hand-off record: on their way under the MPC arithmetic below
+#pragma unroll
+            for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
+            sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
+            load_lane_constants();
+            load_handoff();
+            load_previous_set();
+            q0 = qpos[inst * kDof + j];          // (again: not held across the phase)
+            q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
+            wcqp::wave_lds_fence();              // everything of the kinematics scratch has been read
+            if (j >= 11 && j < 14) {
+                // B_R - B_L, B_C - B_L for the row operations, column cm: B_f = -S(p_f - p_base), column cm = e_cm x (p_f - p_base) -
+                // the products kin_jacobians_kernel forms for the dense base columns
+                double* db = S + OFF_DB;
+                const int cm = j - 11;
+                const double e0 = cm == 0 ? 1.0 : 0.0, e1 = cm == 1 ? 1.0 : 0.0, e2 = cm == 2 ? 1.0 : 0.0;
+                double Bc[3][3];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const double d0 = kdv[3 * f], d1 = kdv[3 * f + 1], d2 = kdv[3 * f + 2];
+                    Bc[f][0] = e1 * d2 - e2 * d1; Bc[f][1] = e2 * d0 - e0 * d2; Bc[f][2] = e0 * d1 - e1 * d0;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { db[r * 3 + cm] = Bc[1][r] - Bc[0][r]; db[9 + r * 3 + cm] = Bc[2][r] - Bc[0][r]; }
+            }
+            if (do_mpc) {                        // the MPC chain's stash back into registers
+                if (j < 2) {
+                    const double* ms = S + K_MS + j * 8;
+                    mreg.s01 = ld2(ms); mreg.s23 = ld2(ms + 2); mreg.s45 = ld2(ms + 4); mreg.s67 = ld2(ms + 6);
+                }
+                if (j < 8) { const double* mh = S + K_MH + j * 3; mreg.ha.x = mh[0]; mreg.ha.y = mh[1]; mreg.hb = mh[2]; }
+            }
+        } else if constexpr (COMPACT) {
             // compact kinematics -> IK hand-off (tick_device.h): one record per joint, [C lin3 | X ...], X = the joint's column of
             // the one frame Jacobian it is on the path of; every other entry of the four Jacobians is a structural zero and the
             // base blocks follow from the three vectors p_frame - p_base.  Five 16-byte loads per slot, whatever the record's
@@ -218,7 +503,11 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TICK) {
             // MPC(t+1), ZMP-CoM law and plant of tick t + 1 for the same four robots, while the Jacobians are on their way
-            if (do_mpc) wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL));
+            if (do_mpc) {
+                // (hull rows in the MPC stash's place, just read back: the attached frames at 312..347 are still needed)
+                if constexpr (KINF) wcqp_tick::tick_mpc_finish_from(td, j, inst, live, tick_now + 1, mreg, m_r0, m_ux, m_uy, reinterpret_cast<double (*)[4]>(S + 348));
+                else wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL));
+            }
             if (j < 6) {
                 const int code = wcqp_tick::contact_code(tick_now, mreg.phase0, td.step_ticks, td.ds_ticks);
                 const double tw = g_sw * wcqp_tick::swing_profile_at(td, mreg.phase0, tick_now);
@@ -236,6 +525,18 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
         for (int m = 0; m < 5; ++m) st[m * 16 + j] = sreg[m];
         st[80 + j] = sreg[5];        // unconditional (slots 87..95 are spare): a predicated store makes hipcc sink the LOAD into the branch, behind the column loads
+        if constexpr (KINF) {
+            // the ACTUAL poses the kinematics phase produced (WalkingModule.cpp:396-410) over the pose block's
+            wcqp::wave_lds_fence();
+            constexpr int K_FR = 312, K_SD = 388;
+            if (j < 12) {
+                const double* FL = S + K_FR, *FRt = S + K_FR + 12;
+                st[j] = j < 3 ? FL[9 + j] : FL[j - 3];
+                st[12 + j] = j < 3 ? FRt[9 + j] : FRt[j - 3];
+            }
+            if (j < 9) st[48 + j] = S[K_FR + 24 + j];
+            if (j < 3) st[66 + j] = S[K_SD + j];
+        }
         if constexpr (TICK) {
             wcqp::wave_lds_fence();
             if (j < 2) { if (!td.kin_mode) st[66 + j] = g_com; st[69 + j] = g_pstar; st[72 + j] = g_vel; }
@@ -309,7 +610,9 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     WCQP_STAMP(2);
     // ---------------- phase 2: base blocks: MIXED pattern check, B_R - B_L, B_C - B_L ---------------------
     bool pat = true;
-    if constexpr (COMPACT) {
+    if constexpr (KINF) {
+        // B_R - B_L, B_C - B_L were written by the kinematics phase
+    } else if constexpr (COMPACT) {
         // the base blocks are B_f = -S(p_f - p_base) by construction (the kinematics kernel wrote the three vectors, not the
         // blocks): column cm of B_f is e_cm x (p_f - p_base), the same products kin_jacobians_kernel forms for the dense columns
         double* db = S + OFF_DB;
@@ -1103,7 +1406,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 // memory for tick t + 1 (joint state, hand-off record, previous active set, live hull rows) is written and read by the
 // same wave, ordered by a workgroup-scope fence per tick.  No per-tick launch, no ramp-up / tail per tick, and a wave
 // whose robots walk a long active set on one tick catches up on the next instead of holding the whole launch.
-template <bool TICK, bool COMPACT>
+template <bool TICK, int JSRC>
 __global__ __launch_bounds__(64, WCQP_IK4_WAVES)
 void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -1119,12 +1422,20 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         // ticks as invariant (a hundred SGPRs live across the whole body, spilled to VGPR lanes); loads through this pointer
         // stay where they are used (memory clobber at the top of an iteration)
         const wcqp_tick::TickDev& td = *tdp;
+        __shared__ __attribute__((aligned(16))) double kmodel[JSRC == 2 ? wcqp_tick::kKinTabSize : 2];
+        __shared__ __attribute__((aligned(16))) double kgains[JSRC == 2 ? 4 * wcqp_tick::kGainsLdsStages : 2];
+        if constexpr (JSRC == 2) {
+            // the kinematic model and the MPC's gain blocks, once per launch: every tick of every robot of this wave reads them from LDS
+            for (int k = threadIdx.x; k < wcqp_tick::kKinTabSize; k += 64) kmodel[k] = td.kin_tab[k];
+            for (int k = threadIdx.x; k < 4 * (td.horizon + 1); k += 64) kgains[k] = td.mpc.Gr[k];
+            wcqp::wave_lds_fence();
+        }
         const int t0 = td.tick2[phase];
 #pragma unroll 1
         for (int k = 0; k < n_inner; ++k) {
             __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop (its registers are all spoken for)
-            ik4_body<TICK, COMPACT>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
-                                    (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1));
+            ik4_body<TICK, JSRC>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
+                                 (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains);
             // tick t + 1 of this wave reads what tick t wrote (other lanes of the same wave): visible before it starts
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -1133,7 +1444,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         // advanceReferenceSignals (WalkingModule.cpp:816): the next launch reads the other copy of the tick index
         if (blockIdx.x == 0 && threadIdx.x == 0) td.tick2[1 - phase] = t0 + n_inner;
     } else {
-        ik4_body<TICK, COMPACT>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem, (int)blockIdx.x);
+        ik4_body<TICK, JSRC>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem, (int)blockIdx.x);
     }
 }
 
@@ -1225,7 +1536,7 @@ int ik4_launch(const IkDeviceParams* d_prm, int batch,
                const double* q, const double* state, double* dq, int* status,
                unsigned* alo, unsigned* aup, double* ferr, int* iters, hipStream_t stream) {
     const unsigned grid = (unsigned)((batch + 3) / 4);
-    hipLaunchKernelGGL((ik4_kernel<false, false>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
+    hipLaunchKernelGGL((ik4_kernel<false, 0>), dim3(grid), dim3(64), 0, stream, d_prm, batch, JL, JR, JN, JC, q, state,
                        dq, status, alo, aup, ferr, iters, nullptr, 0, 1, 0);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
@@ -1234,15 +1545,20 @@ int ik4_launch(const IkDeviceParams* d_prm, int batch,
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_tick::TickDev* td_dev,
                     const double* JL, const double* JR, const double* JN, const double* JC,
                     unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream) {
-    if (n_inner < 1 || (n_inner > 1 && td.kin_mode)) return WCQP_E_INVALID;      // with per-tick kinematics the Jacobians of tick t + 1 come from another launch
+    if (n_inner < 1 || (n_inner > 1 && td.kin_mode && !td.kin_fused)) return WCQP_E_INVALID;      // kinematics in a launch of their own: the Jacobians of tick t + 1 come from another launch
     if (!d_prm || !td_dev || !td.skew || !td.mst || !td.hand || !td.live_A || !td.live_b || !td.live_nc || !td.sel_built) return WCQP_E_INVALID;
     if (td.compact && (!td.jcomp || td.cstride < 1)) return WCQP_E_INVALID;
+    if (td.kin_fused && (!td.kin_tab || !td.kin_mode || td.kin_rounds < 0 || td.kin_rounds > 3 || td.horizon >= wcqp_tick::kGainsLdsStages)) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((td.batch + 3) / 4);
-    if (td.compact)
-        hipLaunchKernelGGL((ik4_kernel<true, true>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
+    const IkDeviceParams* prm = static_cast<const IkDeviceParams*>(d_prm);
+    if (td.kin_fused)
+        hipLaunchKernelGGL((ik4_kernel<true, 2>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
+                           JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
+    else if (td.compact)
+        hipLaunchKernelGGL((ik4_kernel<true, 1>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
                            JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
     else
-        hipLaunchKernelGGL((ik4_kernel<true, false>), dim3(grid), dim3(64), 0, stream, static_cast<const IkDeviceParams*>(d_prm), td.batch,
+        hipLaunchKernelGGL((ik4_kernel<true, 0>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
                            JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;

@@ -21,61 +21,17 @@
 #include <vector>
 #include "wcqp_internal.h"
 #include "tick_device.h"
+#include "kin_device.h"
 
 namespace {
 
-constexpr int kMaxDof = WCQP_KIN_MAX_DOF;     // 32
+using namespace wcqp_kin;
 constexpr int kStateLen = WCQP_IK_STATE_LEN;
 
-constexpr int kMaxRounds = 5;                 // pointer jumping covers 2^5 = 32 >= kMaxDof levels
-
-struct KinDev {
-    int dof, n_rounds, dfs_contig;
-    int up[kMaxRounds][kMaxDof];              // up[0] = parent, up[r + 1][j] = up[r][up[r][j]] (-1: above the root)
-    int sub_end[kMaxDof];                     // last joint of j's subtree when the subtrees are index ranges (dfs_contig)
-    unsigned desc_mask[kMaxDof];              // joints moved by joint j (itself included)
-    unsigned path_mask[3];                    // joints on the path root -> frame f
-    double R0[kMaxDof][9], p0[kMaxDof][3], axis[kMaxDof][3], mass[kMaxDof], com[kMaxDof][3];
-    double root_mass, root_com[3], total_mass;
-    int frame_joint[3];
-    double frame_R[3][9], frame_p[3][3];
-};
-
-__device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
-}
-__device__ __forceinline__ void mat3_vec(const double* A, const double* v, double* o) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) o[r] = A[3 * r] * v[0] + A[3 * r + 1] * v[1] + A[3 * r + 2] * v[2];
-}
-__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
-    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
-}
-// (Ro, po) = (Ra, pa) o (Rb, pb)
-__device__ __forceinline__ void frame_mul(const double* Ra, const double* pa, const double* Rb, const double* pb, double* Ro, double* po) {
-    mat3_mul(Ra, Rb, Ro);
-    double d[3];
-    mat3_vec(Ra, pb, d);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) po[k] = pa[k] + d[k];
-}
-// lane i of a DPP row receives lane i - N (0 below the row start)
-template <int N>
-__device__ __forceinline__ double row_shr0(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + N, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + N, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
 // inclusive prefix sum over each 32-lane half of the wave: four shifts inside the 16-lane DPP rows, then lane 15 / 47
 // goes to every lane of the row above it (row_bcast:15 into rows 1 and 3)
 __device__ __forceinline__ double half_scan(double v) {
-    v += row_shr0<1>(v);
-    v += row_shr0<2>(v);
-    v += row_shr0<4>(v);
-    v += row_shr0<8>(v);
+    v = row_scan(v);
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xa, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xa, 0xf, false);
     return v + __hiloint2double(hi, lo);
@@ -176,15 +132,7 @@ void kin_jacobians_kernel(const KinDev* __restrict__ md, KinShape shp, int batch
     WCQP_KSTAMP(1);
     // own joint: local frame (R0 * Rot(axis, q), p0) relative to the parent's   (Rodrigues)
     double Ra[9];
-    {
-        double sn, cs;
-        sincos(qj, &sn, &cs);
-        const double v = 1.0 - cs;
-        const double Rq[9] = {cs + v * ax[0] * ax[0],         v * ax[0] * ax[1] - sn * ax[2], v * ax[0] * ax[2] + sn * ax[1],
-                              v * ax[1] * ax[0] + sn * ax[2], cs + v * ax[1] * ax[1],         v * ax[1] * ax[2] - sn * ax[0],
-                              v * ax[2] * ax[0] - sn * ax[1], v * ax[2] * ax[1] + sn * ax[0], cs + v * ax[2] * ax[2]};
-        mat3_mul(R0, Rq, Ra);
-    }
+    joint_rotation(R0, ax, qj, Ra);
     WCQP_KSTAMP(2);
     // the tree, in base coordinates, by POINTER JUMPING: after round r the lane's frame is relative to its 2^(r+1)-th
     // ancestor (every joint lane works in every round; a level-by-level walk runs the same code once per tree level
@@ -520,6 +468,34 @@ int kin_enqueue_tick(wcqp_kin_t h, int batch, const wcqp_tick::KinTick& kt, cons
                            J_left, J_right, J_neck, J_com, state, kt);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
+}
+// The model as the tick kernel's fused kinematics phase reads it (tick_device.h: TickDev::kin_tab and the int tables): false when
+// the tree does not qualify (subtrees that are not index ranges, more than 3 pointer-jumping rounds, a joint on two frame paths)
+bool kin_fused_tables(wcqp_kin_t h, std::vector<double>& tab, int up[3][24], int sub_end[24], int frame_joint[3], int* n_rounds) {
+    if (!h) return false;
+    const KinDev& d = h->hd;
+    unsigned m[3]; int stride = 0, off_d = 0;
+    if (!kin_compact_layout(h, m, &stride, &off_d)) return false;
+    if (!d.dfs_contig || d.n_rounds > 3 || d.dof != wcqp_tick::kDof) return false;
+    tab.assign(wcqp_tick::kKinTabSize, 0.0);
+    for (int j = 0; j < d.dof; ++j) {
+        double* r = &tab[(size_t)j * wcqp_tick::kKinTabJoint];
+        for (int k = 0; k < 9; ++k) r[k] = d.R0[j][k];
+        for (int k = 0; k < 3; ++k) { r[9 + k] = d.p0[j][k]; r[12 + k] = d.axis[j][k]; r[15 + k] = d.com[j][k]; }
+        r[18] = d.mass[j];
+        sub_end[j] = d.sub_end[j];
+        for (int q = 0; q < 3; ++q) up[q][j] = d.up[q][j];
+    }
+    for (int f = 0; f < 3; ++f) {
+        double* r = &tab[wcqp_tick::kKinTabFrames + (size_t)f * 12];
+        for (int k = 0; k < 9; ++k) r[k] = d.frame_R[f][k];
+        for (int k = 0; k < 3; ++k) r[9 + k] = d.frame_p[f][k];
+        frame_joint[f] = d.frame_joint[f];
+    }
+    for (int k = 0; k < 3; ++k) tab[wcqp_tick::kKinTabRoot + k] = d.root_com[k];
+    tab[wcqp_tick::kKinTabRoot + 3] = d.root_mass;
+    *n_rounds = d.n_rounds;
+    return true;
 }
 }  // namespace wcqp
 

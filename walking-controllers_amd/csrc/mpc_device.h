@@ -70,6 +70,30 @@ __device__ __forceinline__ void mpc_row_partial(const MpcDeviceConsts& c, int t,
         uy = fma(m * L.g1[k].x, L.r[k].x, fma(m * L.g1[k].y, L.r[k].y, uy));
     }
 }
+// the same with the gain blocks read from a copy of Gr in LDS at the time of use instead of being held in registers from
+// the time of the loads (the tick kernel with fused kinematics: 32 VGPRs less across its kinematics phase); bit-identical
+__device__ __forceinline__ void mpc_window_loads_ref_only(const MpcDeviceConsts& c, int t, const double2* __restrict__ rp, int ref_len, MpcLoads& L)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = t + k * kLanesPerInstance;
+        const int ic = i <= c.N ? i : c.N;
+        const int ir = ic < ref_len ? ic : ref_len - 1;
+        L.r[k] = rp[ir];
+    }
+}
+__device__ __forceinline__ void mpc_row_partial_lds(const MpcDeviceConsts& c, int t, const MpcLoads& L, const double* gr_lds, double& ux, double& uy) {
+    ux = 0.0; uy = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = t + k * kLanesPerInstance;
+        const int ic = i <= c.N ? i : c.N;
+        const double2 g0 = *reinterpret_cast<const double2*>(gr_lds + 4 * ic), g1 = *reinterpret_cast<const double2*>(gr_lds + 4 * ic + 2);
+        const double m = i <= c.N ? 1.0 : 0.0;
+        ux = fma(m * g0.x, L.r[k].x, fma(m * g0.y, L.r[k].y, ux));
+        uy = fma(m * g1.x, L.r[k].x, fma(m * g1.y, L.r[k].y, uy));
+    }
+}
 // stages 64 .. N of a horizon longer than one pass (the shipped controllerHorizon: N = 200), loaded on the spot
 __device__ __forceinline__ void mpc_row_extra_passes(const MpcDeviceConsts& c, int t, const double2* __restrict__ rp, int ref_len, double& ux, double& uy) {
     const double2* gp = reinterpret_cast<const double2*>(c.Gr);

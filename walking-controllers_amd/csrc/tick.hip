@@ -94,8 +94,8 @@ int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s, int n_inner = 1, int 
     d.phase = phase & 1;
     const int B = d.batch;
     const int N = wcqp::mpc_horizon(h->mpc);
-    if (n_inner > 1 && !(h->fused && h->base_elim && !h->kin)) return WCQP_E_INVALID;
-    if (h->kin) {
+    if (n_inner > 1 && !(h->fused && h->base_elim && (!h->kin || d.kin_fused))) return WCQP_E_INVALID;
+    if (h->kin && !d.kin_fused) {
         h->kt.phase = d.phase;
         const int rck = wcqp::kin_enqueue_tick(h->kin, B, h->kt, d.q_des, h->J_left, h->J_right, h->J_neck, h->J_com, d.state, s);
         if (rck != WCQP_OK) return rck;
@@ -184,20 +184,35 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     A_(h->mpc_active, B); A_(h->mpc_margin, B); A_(h->ik_lo, B); A_(h->ik_up, B);
     // skewed tick (base-eliminated fused kernel): state of the MPC chain, MPC -> IK hand-off, one live hull row set per robot
     d.skew = (h->fused && h->base_elim) ? 1 : 0;
-    h->ticks_per_launch = (d.skew && !h->kin) ? (params->ticks_per_launch > 0 ? params->ticks_per_launch : (1 << 20)) : 1;
+
     double* jcomp = nullptr;
     unsigned cm[3] = {0u, 0u, 0u};
     int cstride = 0, coff_d = 0;
-    const bool compact = d.skew && h->kin && !params->kin_dense_handoff && wcqp::kin_compact_layout(h->kin, cm, &cstride, &coff_d);
+    if (params->kin_handoff < 0 || params->kin_handoff > 2) { wcqp_tick_destroy(h); return WCQP_E_INVALID; }
+    const bool masks_ok = d.skew && h->kin && wcqp::kin_compact_layout(h->kin, cm, &cstride, &coff_d);
+    // kinematics fused into the solve kernel (default), or a kinematics launch per tick handing over compact records / dense Jacobians
+    std::vector<double> ktab;
+    const bool fusedk = masks_ok && params->kin_handoff == WCQP_KIN_HANDOFF_FUSED && N < kGainsLdsStages &&
+                        wcqp::kin_fused_tables(h->kin, ktab, d.kin_up, d.kin_sub_end, d.kin_frame_joint, &d.kin_rounds);
+    const bool compact = masks_ok && !fusedk && params->kin_handoff != WCQP_KIN_HANDOFF_DENSE;
     if (d.skew) {
         A_(d.mst, B * 16); A_(d.hand, 2 * B * 10); A_(d.live_A, B * 16); A_(d.live_b, B * 8); A_(d.live_nc, B); A_(d.sel_built, B);
         if (compact) A_(jcomp, B * (size_t)cstride);
+        if (fusedk) {
+            double* kt = nullptr;
+            A_(kt, ktab.size());
+            if (rc == WCQP_OK && hipMemcpy(kt, ktab.data(), ktab.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rc = WCQP_E_HIP;
+            d.kin_tab = kt;
+        }
     }
 #undef A_
     if (rc != WCQP_OK) { wcqp_tick_destroy(h); return rc; }
     wcqp::mpc_device_consts(h->mpc, &d.mpc);
     d.horizon = N; d.hull_sets = (int)hsets;
     if (compact) { d.compact = 1; d.jcomp = jcomp; d.cmaskL = cm[0]; d.cmaskR = cm[1]; d.cmaskN = cm[2]; d.cstride = cstride; d.coff_d = coff_d; }
+    if (fusedk) { d.kin_fused = 1; d.cmaskL = cm[0]; d.cmaskR = cm[1]; d.cmaskN = cm[2]; }
+    // several ticks per launch: whenever a tick is ONE launch of the fused kernel (no kinematics launch in between)
+    h->ticks_per_launch = (d.skew && (!h->kin || fusedk)) ? (params->ticks_per_launch > 0 ? params->ticks_per_launch : (1 << 20)) : 1;
     if (h->kin) {
         double* h0 = nullptr;
         if (dev_alloc(h, &h0, B) != WCQP_OK) { wcqp_tick_destroy(h); return WCQP_E_NOMEM; }

@@ -60,7 +60,17 @@ struct TickDev {
     // three vectors p_frame - p_base that make up the base blocks.  cmask*: joints on the path of the left sole / right sole / neck.
     int compact;
     const double* jcomp; unsigned cmaskL, cmaskR, cmaskN; int cstride, coff_d;
+    // ---- kinematics FUSED into the tick kernel (ik4.hip, JSRC = 2): no kinematics launch, no Jacobian hand-off through memory
+    // at all - the wave that solves a robot's IK first evaluates its forward kinematics and Jacobian columns, 16 lanes per
+    // robot, two joints per lane - and the kernel can then walk through many ticks per launch, like the constant-Jacobian form.
+    // kin_tab: the model as one table of doubles (staged into LDS once per launch): [dof][20] = R0 9 | p0 3 | axis 3 | com 3 |
+    // mass | pad, then [3][12] attached frames R 9 | p 3, then root_com 3, root_mass.
+    int kin_fused, kin_rounds;
+    const double* kin_tab;
+    int kin_up[3][24], kin_sub_end[24], kin_frame_joint[3];
 };
+constexpr int kKinTabJoint = 20, kKinTabFrames = 20 * kDof, kKinTabRoot = kKinTabFrames + 36, kKinTabSize = kKinTabRoot + 4;
+constexpr int kGainsLdsStages = 64;        // fused kinematics: the MPC's gain blocks Gr ((N + 1) x 2 x 2, N <= 63) sit in LDS beside the model
 
 // offset (doubles) of joint c's record inside a robot's compact Jacobian block, and the frame the joint belongs to
 // (0 none, 1 left sole, 2 right sole, 3 neck): records are 4 (CoM column only), 6 (+ neck angular) or 10 (+ a foot's 6) long
@@ -200,19 +210,33 @@ struct TickMpcRegs {
     double2 ha; double hb; int nc;  // live hull row of lane j < 8, row count
     int phase0, built;
 };
+// GAINS_LDS: the gain blocks Gr are read from a copy in LDS at the time of use (gr_lds), not loaded into registers here
+template <bool GAINS_LDS = false>
 __device__ __forceinline__ void tick_mpc_issue(const TickDev& d, int j, long inst, int t, TickMpcRegs& R) {
     const double2* rp = reinterpret_cast<const double2*>(d.ref_traj) + inst * d.traj_len + t;
     R.phase0 = d.phase0[inst];
     R.built = d.sel_built[inst];
     const double2* sp = reinterpret_cast<const double2*>(d.mst + (inst * 2 + (j & 1)) * 8);
     R.s01 = sp[0]; R.s23 = sp[1]; R.s45 = sp[2]; R.s67 = sp[3];
-    wcqp_mpc::mpc_window_loads(d.mpc, j, rp, d.horizon + 1, R.L);
+    if constexpr (GAINS_LDS) wcqp_mpc::mpc_window_loads_ref_only(d.mpc, j, rp, d.horizon + 1, R.L);
+    else wcqp_mpc::mpc_window_loads(d.mpc, j, rp, d.horizon + 1, R.L);
     R.nc = d.live_nc[inst];
     const int jr = j & 7;
     R.ha = reinterpret_cast<const double2*>(d.live_A)[inst * WCQP_HULL_ROWS + jr];
     R.hb = d.live_b[inst * WCQP_HULL_ROWS + jr];
 }
-__device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double (*s_hull)[4]) {
+// tick_mpc_finish = tick_mpc_partial (this lane's share of u0_unc from the loaded window: the window registers die here) +
+// tick_mpc_finish_from (everything else, from the per-axis state records, the hull row and the partial sums)
+template <bool GAINS_LDS = false>
+__device__ __forceinline__ void tick_mpc_partial(const TickDev& d, int j, long inst, int t, const TickMpcRegs& R, const double* gr_lds, double& ux, double& uy) {
+    if constexpr (GAINS_LDS) wcqp_mpc::mpc_row_partial_lds(d.mpc, j, R.L, gr_lds, ux, uy);
+    else wcqp_mpc::mpc_row_partial(d.mpc, j, R.L, ux, uy);
+    if (d.horizon >= 4 * wcqp_mpc::kLanesPerInstance)
+        wcqp_mpc::mpc_row_extra_passes(d.mpc, j, reinterpret_cast<const double2*>(d.ref_traj) + inst * d.traj_len + t, d.horizon + 1, ux, uy);
+}
+// r0: stage 0 of the window (the reference DCM of tick t; meaningful on lane 0)
+__device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double2 r0, double ux, double uy,
+                                                     double (*s_hull)[4]) {
     // contact pair of tick t; the live row set follows it (WalkingController::setConvexHullConstraint switches rows only
     // when the pair changes, ...PredictiveController.cpp:369-374)
     const int code = contact_code(t, R.phase0, d.step_ticks, d.ds_ticks);
@@ -238,10 +262,6 @@ __device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long in
         R.hb = d.live_b[inst * WCQP_HULL_ROWS + jr];
     }
     // ---- the condensed MPC (mpc_device.h): x0 = measured DCM, u_prev = previous output (MPCSolver.cpp:244-245)
-    double ux, uy;
-    wcqp_mpc::mpc_row_partial(d.mpc, j, R.L, ux, uy);
-    if (d.horizon >= 4 * wcqp_mpc::kLanesPerInstance)
-        wcqp_mpc::mpc_row_extra_passes(d.mpc, j, reinterpret_cast<const double2*>(d.ref_traj) + inst * d.traj_len + t, d.horizon + 1, ux, uy);
     {
         // lane 0 holds the x axis' record, lane 1 the y axis': the y entries come over by DPP (row_shl:1)
         const double dcm_y = wcqp_mpc::row_move<0x101>(R.s67.x), up_y = wcqp_mpc::row_move<0x101>(R.s23.y);
@@ -253,13 +273,13 @@ __device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long in
     wcqp_mpc::mpc_row_finish(d.mpc, j, ux, uy, R.nc, j < WCQP_HULL_ROWS ? R.ha.x : 0.0, j < WCQP_HULL_ROWS ? R.ha.y : 0.0,
                              j < WCQP_HULL_ROWS ? R.hb : 0.0, s_hull, u0x, u0y, st, act, margin);
     const bool mpc_ok = st == WCQP_STATUS_SOLVED || st == WCQP_STATUS_OUTSIDE_HULL;
-    const double r_y = wcqp_mpc::row_move<0x111>(R.L.r[0].y);          // lane 1 <- lane 0 (row_shr:1)
+    const double r_y = wcqp_mpc::row_move<0x111>(r0.y);          // lane 1 <- lane 0 (row_shr:1)
     if (j < 2 && live) {
         const int ax = j;
         const double c_ref0 = R.s01.x, v_ref_prev = R.s01.y, com = R.s23.x, u_prev = R.s23.y;
         const double p_star0 = R.s45.x, v_star_prev = R.s45.y, xi = R.s67.x;
         // StableDCMModel::integrateModel (StableDCMModel.cpp:63-90), Tustin integrator
-        const double rr = ax == 0 ? R.L.r[0].x : r_y;        // reference DCM of tick t: stage 0 of the window (lane 0 holds it)
+        const double rr = ax == 0 ? r0.x : r_y;        // reference DCM of tick t: stage 0 of the window (lane 0 holds it)
         const double vr = -d.omega * (c_ref0 - rr);
         const double c_ref = c_ref0 + 0.5 * d.dT * (vr + v_ref_prev);
         const double u = mpc_ok ? (ax == 0 ? u0x : u0y) : u_prev;        // hold the last command on failure
@@ -277,6 +297,13 @@ __device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long in
         if (ax == 0) hd[8] = mpc_ok ? 1.0 : 0.0;
         if (t < d.log_ticks) d.u0_log[((size_t)t * d.batch + inst) * 2 + ax] = u;
     }
+}
+template <bool GAINS_LDS = false>
+__device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double (*s_hull)[4],
+                                                const double* gr_lds = nullptr) {
+    double ux, uy;
+    tick_mpc_partial<GAINS_LDS>(d, j, inst, t, R, gr_lds, ux, uy);
+    tick_mpc_finish_from(d, j, inst, live, t, R, R.L.r[0], ux, uy, s_hull);
 }
 // swing_profile with the instance's phase offset already in a register
 __device__ __forceinline__ double swing_profile_at(const TickDev& d, int phase0, int t) {
