@@ -86,6 +86,11 @@ def main():
                          "per launch); dense / compact = a kinematics launch per tick handing over four dense Jacobians / per-joint records (A/B; same results)")
     ap.add_argument("--ticks-per-launch", type=int, default=0, help="tick workload without per-tick kinematics: ticks the fused kernel runs per launch (0 = the library's default, 1 = one launch per tick)")
     ap.add_argument("--tick-cold-ik", action="store_true", help="tick workload: no IK hot start (every tick walks the active set from the unconstrained optimum)")
+    ap.add_argument("--plan-ways", type=int, default=4,
+                    help="qp workload: the timed steps as ONE launch (wcqp_qp_plan_*): consecutive steps are independent batches, so a wavefront "
+                         "owns four robots and walks through the steps on its own, the MPC of a step in the shadow of its IK's Jacobian loads; "
+                         "W wavefronts share a robot group (way w takes steps w, w + W, ...; each way has its own output buffers, like a "
+                         "pipeline).  0 = one launch per step on --pipelines streams (round-2 form)")
     ap.add_argument("--step-graph", action="store_true", help="qp workload: replay ONE hipGraph that holds the timed steps as P parallel chains (one per "
                     "pipeline) instead of enqueueing them launch by launch.  Measured and left off: 8.9-9.2 us per step against 8.5-9.1 in "
                     "the driver's 20-step form, 8.9 against 7.0 at 200 steps (profiles/r03_step_graph_ab.txt)")
@@ -152,7 +157,12 @@ def main():
     set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
     K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
-    P = args.pipelines if args.pipelines > 0 else (1 if (args.exchange and dist is not None) else 3)
+    use_plan = (args.plan_ways > 0 and not (args.exchange and dist is not None) and args.streams in (0, 1) and args.ik_jac == "mixed"
+                and NH < 64 and not args.step_graph)
+    if use_plan:
+        P = args.pipelines if args.pipelines > 0 else args.plan_ways           # one output buffer set per way
+    else:
+        P = args.pipelines if args.pipelines > 0 else (1 if (args.exchange and dist is not None) else 3)
 
     def outputs():
         return dict(u0=torch.zeros(B, 2, dtype=torch.float64, device=dev), mstat=torch.zeros(B, dtype=torch.int32, device=dev),
@@ -179,7 +189,7 @@ def main():
     stream_mpc = torch.cuda.Stream(dev) if two_streams else stream
     sp_mpc = stream_mpc.cuda_stream
     # pipeline 0 = (stream, stream_mpc); further pipelines get streams of their own
-    pipes = [(stream, stream_mpc)] + [(torch.cuda.Stream(dev), torch.cuda.Stream(dev) if two_streams else None) for _ in range(P - 1)]
+    pipes = [(stream, stream_mpc)] + [((stream, None) if use_plan else (torch.cuda.Stream(dev), torch.cuda.Stream(dev) if two_streams else None)) for _ in range(P - 1)]
     pipes = [(a, b if b is not None else a) for a, b in pipes]
     all_streams = []
     for pr in pipes:
@@ -296,6 +306,7 @@ def main():
     # its stream, the chains forked from and joined into the capture stream), captured from the very wcqp_qp_enqueue_steps
     # call the launch-by-launch form makes; set-up: capture, instantiate, one replay (the first launch of a graph uploads
     # it).  A/B'd in round 3 and left OFF: the graph's dependent kernel nodes are dispatched no faster than the streams do it.
+    plan = wca.capi.QpPlan(mpc, ik, B, recs, ways=P) if (use_plan and recs is not None) else None
     step_graph = None
     if recs is not None and args.step_graph:
         try:
@@ -315,7 +326,9 @@ def main():
             torch.cuda.synchronize(dev)
     # ---- the timed region: K steps, nothing but the launches (no events, no host reads) ----------------------------
     t0 = time.perf_counter()
-    if step_graph is not None:
+    if plan is not None:
+        plan.enqueue(sp)
+    elif step_graph is not None:
         step_graph.replay()
     elif recs is not None:
         wca.capi.qp_enqueue_steps(mpc, ik, B, recs)
@@ -396,7 +409,32 @@ def main():
     ik_auto_ms = kernel_ms(lambda d: launch_ik(d, ik_auto), pipes[0][0], True)
 
     # the launch the timed region is made of when a step's two calls share a stream: IK and MPC workgroups in one grid
-    pair_mode = recs is not None and not two_streams and args.ik_jac != "general"
+    # the launch the timed region is made of in plan mode: qp_plan_kernel over n records (cold: rotating over the K input sets;
+    # resident: one set), timed alone with events; per-step time = launch / n
+    plan_ms = plan_ms_res = None
+    if plan is not None:
+        def plan_pass(cold, n):
+            r2 = (wca.capi.QpStep * n)()
+            for t_ in range(n):
+                d, k = sets[t_ % K if cold else 0], t_ % P
+                o, m, q_ = optr[k], d["_mpc"], d["_ik"]
+                r = r2[t_]
+                r.x0, r.ref, r.ref_len, r.u_prev, r.hull_A, r.hull_b, r.hull_nc = m[0], m[1], N1, m[2], m[3], m[4], m[5]
+                r.u0, r.mpc_status, r.mpc_active, r.mpc_margin = o["u0"], o["mstat"], o["mact"], o["mmar"]
+                r.J_left, r.J_right, r.J_neck, r.J_com, r.q, r.state = q_
+                r.dq, r.ik_status, r.active_lower, r.active_upper, r.foot_err, r.iters = o["dq"], o["istat"], o["ilo"], o["iup"], None, o["iit"]
+            pl = wca.capi.QpPlan(mpc, ik, B, r2, ways=P)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pl.enqueue(sp)
+            torch.cuda.synchronize(dev)
+            e0.record(stream); pl.enqueue(sp); e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1)
+            pl.close()
+            return ms / n
+        n_plan = max(24, 2 * K, args.steps)
+        plan_ms, plan_ms_res = plan_pass(True, n_plan), plan_pass(False, n_plan)
+    pair_mode = plan is None and recs is not None and not two_streams and args.ik_jac != "general"
     pair_ms = pair_ms_res = None
     if pair_mode:
         one = {}
@@ -427,16 +465,30 @@ def main():
             "batch_per_gpu": B, "global_batch": B * world, "horizon": NH, "dof": 23,
             "input_sets": K, "input_bytes_per_set": set_bytes, "ik_jacobian_structure": args.ik_jac, "pipelines": P,
             "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
-            "timed_steps_enqueued_as": ("one hipGraph launch: %d parallel chains of one-launch steps" % P) if step_graph is not None else "one wcqp_qp_enqueue_steps call, launch by launch",
+            "timed_steps_enqueued_as": ("ONE launch (wcqp_qp_plan_enqueue): qp_plan_kernel walks through the %d steps, %d wavefronts per robot group" % (args.steps, P)) if plan is not None
+                                       else (("one hipGraph launch: %d parallel chains of one-launch steps" % P) if step_graph is not None else "one wcqp_qp_enqueue_steps call, launch by launch"),
             "timed_region": "barrier + torch.cuda.synchronize() -> K steps -> completion events of every stream used (hipEventSynchronize), "
                             "MAX over ranks; the device-wide synchronize that follows adds %.0f us of host time with the device idle "
                             "(ms_per_step_incl_device_sync)" % (1e6 * (elapsed_sync - elapsed)),
             "ms_per_step_incl_device_sync": 1e3 * elapsed_sync / args.steps, "value_incl_device_sync": total_qp / elapsed_sync,
-            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ("; MPC and IK of a step in one launch" if not exch else "")) + ("; %d independent batches in flight (step i -> pipeline i %% %d)" % (P, P) if P > 1 else ""),
+            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ("; MPC and IK of a step in one launch" if not exch else "")) + (("; %d wavefronts per robot group (step i -> way i %% %d)" % (P, P) if plan is not None else "; %d independent batches in flight (step i -> pipeline i %% %d)" % (P, P)) if P > 1 else ""),
         },
         # the dominant kernel of the timed region: the one-launch step (IK + MPC workgroups; algorithmic bytes = both QPs'
         # per robot-tick) - or the IK kernel where the two calls are separate launches
         "roofline": ({
+            # the dominant kernel IS the timed region: one launch that walks through the steps.  achieved = algorithmic bytes of
+            # a step (6296 B per robot-tick) x steps per launch / launch duration (events, a pass of its own with
+            # max(24, 2 K, steps) records; rocprofv3's average duration of qp_plan_kernel / its records is the same number)
+            "bound": "hbm", "kernel": "qp_plan_kernel",
+            "achieved": (IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "avg_launch_ms": plan_ms * n_plan, "steps_per_launch": n_plan, "avg_ms_per_step": plan_ms,
+            "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B * n_plan,
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (> the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6),
+            "frac_resident_inputs": (IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms_per_step_resident_inputs": plan_ms_res,
+            "timed_region": {"achieved": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9,
+                             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+        } if plan is not None else {
             "bound": "hbm", "kernel": "qp_pair_kernel",
             "achieved": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -481,7 +533,7 @@ def main():
             if tj.get("csrc_sha256") != wca.capi.source_hash():
                 out["roofline"]["traffic_note"] = "profiles/traffic.json was measured on other kernel sources (re-run tools/pmc/collect.sh + make_traffic.py): not quoted"
             elif tr:
-                out["roofline"]["traffic"] = tr.get("pair_hbm_bytes_per_launch" if pair_mode else "ik_hbm_bytes_per_launch")
+                out["roofline"]["traffic"] = tr.get("plan_hbm_bytes_per_step") if plan is not None else tr.get("pair_hbm_bytes_per_launch" if pair_mode else "ik_hbm_bytes_per_launch")
         except Exception:
             pass
 

@@ -288,6 +288,22 @@ typedef struct wcqp_qp_step {
 int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch,
                           int32_t n_steps, const wcqp_qp_step* steps, int32_t* n_done);
 
+/* A PLAN of steps: the records of wcqp_qp_enqueue_steps, uploaded once and replayed as ONE launch.  Consecutive steps of the
+ * BASELINE workload are independent cold-start batches, so nothing has to order them on the device: a wavefront owns four
+ * robots and walks through the records on its own - no launch, ramp-up or tail per step, the MPC of a record solved on the
+ * IK's lanes while its Jacobians are in flight - and `ways` wavefronts share a robot group, way w taking records w, w + ways,
+ * ... (two ways fill both wave slots of every SIMD at the BASELINE batch of 4096).  Records of DIFFERENT ways run
+ * concurrently: they must not share output arrays (give each way its own, like the pipelines of separate streams).  Every
+ * record needs both parts; the stream fields of the records are ignored (wcqp_qp_plan_enqueue names the stream).
+ * WCQP_E_UNSUPPORTED unless the IK handle runs its default kernel with jacobian_structure = WCQP_IK_JAC_MIXED and the MPC
+ * horizon is <= 63: use wcqp_qp_enqueue_steps then.  Same results as the single calls, bit for bit.  The arrays the
+ * records point to must stay valid while the plan is used; the handles must outlive the plan. */
+typedef struct wcqp_qp_plan_s* wcqp_qp_plan_t;
+int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_steps, const wcqp_qp_step* steps, int32_t ways,
+                        wcqp_qp_plan_t* out);
+int wcqp_qp_plan_enqueue(wcqp_qp_plan_t plan, void* stream);      /* enqueue only; graph-capturable */
+int wcqp_qp_plan_destroy(wcqp_qp_plan_t plan);
+
 /* =====================================================================================
  * Batched kinematics: forward kinematics of a kinematic tree and the free-floating
  * Jacobians in MIXED representation that the QP-IK consumes - what the reference obtains from

@@ -1,0 +1,68 @@
+"""Run by tests/test_gpu_parity.py::test_qp_plan_equals_the_single_calls in a process of its own (torch first, then libwcqp):
+a plan of 7 records (wcqp_qp_plan_*: ONE launch walks through them, `ways` wavefronts per robot group, each way with its own
+output buffers) against the single wcqp_mpc_solve_device / wcqp_ik_solve_device calls of the same records, bit for bit."""
+import os, sys
+import numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import walking_controllers_amd as wca
+
+
+def main(B, ways, R=7):
+    dev = torch.device("cuda", 0)
+    mpc, ik = wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, jacobian_structure=wca.IK_JAC_MIXED)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    sets = []
+    for seed in range(R):
+        mb, ib = wca.synth.synth_mpc_batch(B, seed=50 + seed, uprev_sigma=0.03), wca.synth.synth_ik_batch(B, seed=150 + seed)
+        sets.append(({k: t(mb[k]) for k in ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc")},
+                     {k: t(ib[k]) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")}))
+
+    def outs():
+        return dict(u0=torch.zeros(B, 2, dtype=torch.float64, device=dev), ms=torch.full((B,), -1, dtype=torch.int32, device=dev),
+                    ma=torch.zeros(B, dtype=torch.int32, device=dev), mm=torch.zeros(B, dtype=torch.float64, device=dev),
+                    dq=torch.zeros(B, 23, dtype=torch.float64, device=dev), st=torch.full((B,), -1, dtype=torch.int32, device=dev),
+                    lo=torch.zeros(B, dtype=torch.int32, device=dev), up=torch.zeros(B, dtype=torch.int32, device=dev),
+                    fe=torch.zeros(B, 12, dtype=torch.float64, device=dev), it=torch.zeros(B, dtype=torch.int32, device=dev))
+    ref_o, got_o = [outs() for _ in range(R)], [outs() for _ in range(R)]
+    N1 = sets[0][0]["ref"].shape[1]
+    torch.cuda.synchronize()
+    for (m, i), o in zip(sets, ref_o):
+        mpc.solve_device(B, m["x0"].data_ptr(), m["ref"].data_ptr(), N1, m["u_prev"].data_ptr(), m["hull_A"].data_ptr(),
+                         m["hull_b"].data_ptr(), m["hull_nc"].data_ptr(), o["u0"].data_ptr(), o["ms"].data_ptr(), o["ma"].data_ptr(), o["mm"].data_ptr(), 0)
+        ik.solve_device(B, i["J_left"].data_ptr(), i["J_right"].data_ptr(), i["J_neck"].data_ptr(), i["J_com"].data_ptr(), i["q"].data_ptr(),
+                        i["state"].data_ptr(), o["dq"].data_ptr(), o["st"].data_ptr(), o["lo"].data_ptr(), o["up"].data_ptr(), o["fe"].data_ptr(), o["it"].data_ptr(), 0)
+    torch.cuda.synchronize()
+    recs = (wca.capi.QpStep * R)()
+    for n, ((m, i), o) in enumerate(zip(sets, got_o)):     # every record its own outputs: whatever the way, nothing is shared
+        r = recs[n]
+        r.x0, r.ref, r.ref_len, r.u_prev = m["x0"].data_ptr(), m["ref"].data_ptr(), N1, m["u_prev"].data_ptr()
+        r.hull_A, r.hull_b, r.hull_nc = m["hull_A"].data_ptr(), m["hull_b"].data_ptr(), m["hull_nc"].data_ptr()
+        r.u0, r.mpc_status, r.mpc_active, r.mpc_margin = o["u0"].data_ptr(), o["ms"].data_ptr(), o["ma"].data_ptr(), o["mm"].data_ptr()
+        r.J_left, r.J_right, r.J_neck, r.J_com = (i[k].data_ptr() for k in ("J_left", "J_right", "J_neck", "J_com"))
+        r.q, r.state = i["q"].data_ptr(), i["state"].data_ptr()
+        r.dq, r.ik_status, r.active_lower, r.active_upper = o["dq"].data_ptr(), o["st"].data_ptr(), o["lo"].data_ptr(), o["up"].data_ptr()
+        r.foot_err, r.iters = o["fe"].data_ptr(), o["it"].data_ptr()
+    plan = wca.capi.QpPlan(mpc, ik, B, recs, ways=ways)
+    st = torch.cuda.Stream(dev)
+    plan.enqueue(st.cuda_stream)
+    plan.enqueue(st.cuda_stream)            # replay: same results
+    torch.cuda.synchronize()
+    for n, (a, b) in enumerate(zip(ref_o, got_o)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (B, ways, n, k)
+    assert (got_o[0]["ms"] == 0).all() and sum(int((o["ma"] != 0).sum()) for o in got_o) > 0          # hull rows really bind somewhere
+    plan.close()
+    # a plan needs what one launch can do: an IK handle with the general fall-back behind it is refused
+    try:
+        wca.capi.QpPlan(mpc, wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, jacobian_structure=wca.IK_JAC_AUTO), B, recs)
+        raise AssertionError("a plan on an AUTO-structure handle must be refused")
+    except wca.WcqpError:
+        pass
+
+
+if __name__ == "__main__":
+    for B, ways in ((1, 1), (5, 3), (777, 2), (4096, 2), (4096, 9)):      # ragged batches; more ways than records
+        main(B, ways)
+    print("plan ok")

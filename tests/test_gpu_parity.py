@@ -461,6 +461,17 @@ def test_qp_enqueue_steps_equals_the_single_calls():
 
 
 @pytest.mark.gpu
+def test_qp_plan_equals_the_single_calls():
+    """wcqp_qp_plan_*: a plan's ONE launch (wavefronts walking through the records, the MPC on the IK's lanes, several
+    wavefronts per robot group) gives what the single calls give for every record, bit for bit - ragged batches, the BASELINE
+    batch, more ways than records, replay (tests/helpers/plan_check.py, a process of its own)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "plan_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "plan ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_timed_launch_shape_against_goldens():
     """The launch shape bench.py times: BASELINE batch 4096, the bench's own inputs (MPC seed 1234 = golden
     mpc_cfg2_b4096, IK seed 4321 at v_max 0.5 = golden ik_qpoases_v050_b1024), 12 records handed over in ONE

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "wcqp_hull_from_feet_device", "wcqp_hull_from_feet_host",
     "wcqp_kin_create", "wcqp_kin_destroy", "wcqp_kin_jacobians_device", "wcqp_kin_jacobians_host",
     "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download", "wcqp_tick_splice_reference",
-    "wcqp_qp_enqueue_steps",
+    "wcqp_qp_enqueue_steps", "wcqp_qp_plan_create", "wcqp_qp_plan_enqueue", "wcqp_qp_plan_destroy",
 )
 
 
@@ -82,6 +82,30 @@ def qp_enqueue_steps(mpc, ik, batch, steps):
     check(lib().wcqp_qp_enqueue_steps(mpc._h if mpc is not None else None, ik._h if ik is not None else None, int(batch),
                                       len(steps), steps, C.byref(done)), "wcqp_qp_enqueue_steps")
     return done.value
+
+
+class QpPlan:
+    """wcqp_qp_plan_*: the records of qp_enqueue_steps uploaded once, replayed as ONE launch that walks through them; `ways`
+    wavefronts share a robot group (way w takes records w, w + ways, ...: records of different ways need their own outputs)."""
+
+    def __init__(self, mpc, ik, batch, steps, ways=1):
+        self._h = C.c_void_p()
+        self._keep = (mpc, ik, steps)
+        check(lib().wcqp_qp_plan_create(mpc._h, ik._h, int(batch), len(steps), steps, int(ways), C.byref(self._h)), "wcqp_qp_plan_create")
+
+    def enqueue(self, stream=0):
+        check(lib().wcqp_qp_plan_enqueue(self._h, stream or None), "wcqp_qp_plan_enqueue")
+
+    def close(self):
+        if self._h:
+            lib().wcqp_qp_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class KinParams(C.Structure):
@@ -153,6 +177,9 @@ def lib() -> C.CDLL:
         L.wcqp_tick_download.argtypes = [C.c_void_p, C.POINTER(TickOutputs)]
         L.wcqp_tick_splice_reference.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.wcqp_qp_enqueue_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.POINTER(C.c_int32)]
+        L.wcqp_qp_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.c_int32, C.POINTER(C.c_void_p)]
+        L.wcqp_qp_plan_enqueue.argtypes = [C.c_void_p, C.c_void_p]
+        L.wcqp_qp_plan_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 

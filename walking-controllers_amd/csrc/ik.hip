@@ -603,6 +603,59 @@ int qp_pair_enqueue(wcqp_mpc_t mpc, wcqp_ik_t h, int batch, const wcqp_qp_step& 
 }
 }  // namespace wcqp
 
+// ---- plans of steps (include/wcqp.h: wcqp_qp_plan_*) ------------------------------------------------------------------
+struct wcqp_qp_plan_s {
+    wcqp_mpc_t mpc = nullptr;
+    wcqp_ik_t ik = nullptr;
+    int batch = 0, n_steps = 0, ways = 1;
+    wcqp_qp_step* d_recs = nullptr;
+};
+
+extern "C" {
+
+int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_steps, const wcqp_qp_step* steps, int32_t ways,
+                        wcqp_qp_plan_t* out) {
+    if (!mpc || !ik || !out || batch < 1 || n_steps < 1 || !steps || ways < 1) return WCQP_E_INVALID;
+    // one launch walks through the records: that is the base-eliminated kernel on Jacobians the caller declares MIXED (no
+    // fall-back launch behind it), with the MPC on the IK's lanes (a horizon of one pass: N <= 63)
+    const bool want4 = ik->p.algorithm == WCQP_IK_ALG_BASE_ELIM || ik->p.algorithm == WCQP_IK_ALG_DEFAULT;
+    if (!(want4 && ik->hp.fast_ok && ik->p.jacobian_structure == WCQP_IK_JAC_MIXED)) return WCQP_E_UNSUPPORTED;
+    if (wcqp::mpc_horizon(mpc) >= 4 * wcqp_mpc::kLanesPerInstance) return WCQP_E_UNSUPPORTED;
+    for (int k = 0; k < n_steps; ++k) {
+        const wcqp_qp_step& s = steps[k];
+        if (!s.x0 || !s.ref || s.ref_len < 1 || !s.u_prev || !s.hull_A || !s.hull_b || !s.hull_nc || !s.u0 || !s.mpc_status) return WCQP_E_INVALID;
+        if (!s.J_left || !s.J_right || !s.J_neck || !s.J_com || !s.q || !s.state || !s.dq || !s.ik_status) return WCQP_E_INVALID;
+    }
+    int rc = ensure_device(ik);
+    if (rc == WCQP_OK) rc = wcqp::mpc_prepare(mpc);
+    if (rc != WCQP_OK) return rc;
+    wcqp_qp_plan_s* p = new (std::nothrow) wcqp_qp_plan_s();
+    if (!p) return WCQP_E_NOMEM;
+    p->mpc = mpc; p->ik = ik; p->batch = batch; p->n_steps = n_steps; p->ways = ways < n_steps ? ways : n_steps;
+    if (hipMalloc(reinterpret_cast<void**>(&p->d_recs), (size_t)n_steps * sizeof(wcqp_qp_step)) != hipSuccess) { delete p; return WCQP_E_NOMEM; }
+    if (hipMemcpy(p->d_recs, steps, (size_t)n_steps * sizeof(wcqp_qp_step), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p->d_recs); delete p; return WCQP_E_HIP;
+    }
+    *out = p;
+    return WCQP_OK;
+}
+
+int wcqp_qp_plan_enqueue(wcqp_qp_plan_t p, void* stream) {
+    if (!p) return WCQP_E_INVALID;
+    wcqp_mpc::MpcDeviceConsts c;
+    wcqp::mpc_device_consts(p->mpc, &c);
+    return wcqp_ik::ik4_launch_plan(p->ik->d_prm, p->batch, p->d_recs, p->n_steps, p->ways, c, (hipStream_t)stream);
+}
+
+int wcqp_qp_plan_destroy(wcqp_qp_plan_t p) {
+    if (!p) return WCQP_E_INVALID;
+    if (p->d_recs) (void)hipFree(p->d_recs);
+    delete p;
+    return WCQP_OK;
+}
+
+}  // extern "C"
+
 extern "C" {
 
 int wcqp_ik_solve_host(wcqp_ik_t h, int32_t batch,

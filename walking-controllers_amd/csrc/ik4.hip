@@ -110,9 +110,19 @@ __device__ __forceinline__ void swap16(double& a, double& b) {
 __device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 
+// the DCM-MPC of the same robots riding along with their IK (qp_pair_kernel: in workgroups of its own; PAIR: on the IK's lanes)
+struct MpcPairArgs {
+    wcqp_mpc::MpcDeviceConsts c;
+    const double* x0; const double* ref; int ref_len; const double* u_prev;
+    const double* hull_A; const double* hull_b; const int* hull_nc;
+    double* u0; int* status; unsigned* active; double* margin;
+};
+
+// PAIR (a plan of steps, wcqp_qp_plan_*): the wave also solves the DCM-MPC QP of its four robots, its loads issued in front
+// of the IK's and its arithmetic running while the Jacobians are in flight (what the tick kernel does with the MPC of the next tick).
 // JSRC: where the Jacobians come from - 0 the four dense arrays of the ABI, 1 the compact per-joint records of the tick's
 // kinematics kernel (tick_device.h), 2 the kinematics phase of this kernel itself (no hand-off through memory at all)
-template <bool TICK, int JSRC = 0>
+template <bool TICK, int JSRC = 0, bool PAIR = false>
 __device__ __forceinline__
 void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -121,14 +131,16 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 double* __restrict__ dq_out, int* __restrict__ status_out,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev& td, double (*smem)[PER_INST], int blk,
-                const int tick_now = 0, const bool do_mpc = true, const double* kmodel = nullptr, const double* gr_lds = nullptr)
+                const int tick_now = 0, const bool do_mpc = true, const double* kmodel = nullptr, const double* gr_lds = nullptr,
+                const MpcPairArgs* pm = nullptr)
 {
+    static_assert(!(TICK && PAIR), "the tick kernel carries its own MPC chain");
     constexpr bool COMPACT = JSRC == 1;
     constexpr bool KINF = JSRC == 2;
     int lane_id = threadIdx.x;
     // inside the tick kernel's loop over ticks: keeps hipcc from hoisting every per-lane address and constant of the body
     // out of the loop (they would all be live across the whole body: +100 VGPRs and spills)
-    if constexpr (TICK) __asm__ volatile("" : "+v"(lane_id));
+    if constexpr (TICK || PAIR) __asm__ volatile("" : "+v"(lane_id));
     const int lane = lane_id;
     const int grp = lane >> 4;
     const int j = lane & 15;
@@ -173,6 +185,15 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     // behind them, and its arithmetic runs while the Jacobians are in flight; IK(t) reads what MPC(t) left in the hand-off
     // record one launch ago (the first launch after an upload is primed by tick_mpc_prime_kernel, tick.hip).
     wcqp_tick::TickMpcRegs mreg;
+    double2 p_xs = make_double2(0.0, 0.0), p_up = make_double2(0.0, 0.0);
+    if constexpr (PAIR) {
+        const double2* rp = reinterpret_cast<const double2*>(pm->ref) + inst * pm->ref_len;
+        wcqp_mpc::mpc_window_loads(pm->c, j, rp, pm->ref_len, mreg.L);
+        if (j == 0) { p_xs = reinterpret_cast<const double2*>(pm->x0)[inst]; p_up = reinterpret_cast<const double2*>(pm->u_prev)[inst]; }
+        mreg.nc = pm->hull_nc[inst];
+        mreg.ha = make_double2(0.0, 0.0); mreg.hb = 0.0;
+        if (j < WCQP_HULL_ROWS) { mreg.ha = reinterpret_cast<const double2*>(pm->hull_A)[inst * WCQP_HULL_ROWS + j]; mreg.hb = pm->hull_b[inst * WCQP_HULL_ROWS + j]; }
+    }
     if constexpr (TICK) { if (do_mpc) wcqp_tick::tick_mpc_issue<KINF>(td, j, inst, tick_now + 1, mreg); else mreg.phase0 = td.phase0[inst]; }
     double2 cr0[5], cr1[5], cdv[5];        // COMPACT: the two joint records and the three vectors p_frame - p_base, as loaded
     int ckind0 = 0, ckind1 = 0;
@@ -501,6 +522,21 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         for (int r = 0; r < 3; ++r) { a0[15 + r] = jn[r * kNV + fc0]; a1[15 + r] = jn[r * kNV + fc1]; }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PAIR) {
+            // the DCM-MPC QP of the same four robots while the Jacobians are on their way: the operations of mpc_row_solve, in its order
+            double ux, uy, u0x, u0y, margin;
+            int mst_;
+            unsigned mact;
+            wcqp_mpc::mpc_row_partial(pm->c, j, mreg.L, ux, uy);
+            if (j == 0) wcqp_mpc::mpc_row_add_state(pm->c, p_xs, p_up, ux, uy);
+            wcqp_mpc::mpc_row_finish(pm->c, j, ux, uy, mreg.nc, mreg.ha.x, mreg.ha.y, mreg.hb, reinterpret_cast<double (*)[4]>(S + OFF_COL), u0x, u0y, mst_, mact, margin);
+            if (j == 0 && live) {
+                reinterpret_cast<double2*>(pm->u0)[inst] = make_double2(u0x, u0y);
+                pm->status[inst] = mst_;
+                if (pm->active) pm->active[inst] = mact;
+                if (pm->margin) pm->margin[inst] = margin;
+            }
+        }
         if constexpr (TICK) {
             // MPC(t+1), ZMP-CoM law and plant of tick t + 1 for the same four robots, while the Jacobians are on their way
             if (do_mpc) {
@@ -1467,12 +1503,6 @@ void tick_mpc_prime_kernel(wcqp_tick::TickDev td, int t)
 // stream): workgroups 0 .. ik_blocks-1 are the IK kernel above, the rest the DCM-MPC kernel of mpc.hip (same device
 // functions, same results).  At the BASELINE batch each is one wave per SIMD, so the MPC waves run in the slots the IK
 // waves leave idle while their inputs are on the way, and the host pays one launch per step instead of two.
-struct MpcPairArgs {
-    wcqp_mpc::MpcDeviceConsts c;
-    const double* x0; const double* ref; int ref_len; const double* u_prev;
-    const double* hull_A; const double* hull_b; const int* hull_nc;
-    double* u0; int* status; unsigned* active; double* margin;
-};
 __global__ __launch_bounds__(64, WCQP_IK4_WAVES)
 void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                     const double* __restrict__ JL, const double* __restrict__ JR,
@@ -1511,9 +1541,40 @@ void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     ik4_body<false>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem, blk);
 }
 
+// A PLAN of steps (wcqp_qp_plan_*): every record is one batch of robot-ticks - one DCM-MPC QP and one QP-IK per robot, as
+// wcqp_qp_enqueue_steps would launch it - and ONE launch walks through all of them.  Consecutive records are independent
+// batches, so nothing orders them: workgroup (way w, robot group g) solves robots 4g .. 4g+3 of records w, w + ways, ... on
+// its own - no launch, ramp-up or tail per step, the MPC of a record in the shadow of its IK's Jacobian loads, and with
+// `ways` workgroups per robot group the BASELINE batch (1024 robot groups) fills both wave slots of every SIMD.
+__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
+void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups,
+                    wcqp_mpc::MpcDeviceConsts c)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
+    const int way = (int)blockIdx.x / groups, blk = (int)blockIdx.x % groups;
+#pragma unroll 1
+    for (int r = way; r < n_steps; r += ways) {
+        __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop
+        const wcqp_qp_step& s = recs[r];
+        MpcPairArgs m{c, s.x0, s.ref, s.ref_len, s.u_prev, s.hull_A, s.hull_b, s.hull_nc, s.u0, s.mpc_status, s.mpc_active, s.mpc_margin};
+        ik4_body<false, 0, true>(prm, batch, s.J_left, s.J_right, s.J_neck, s.J_com, s.q, s.state, s.dq, s.ik_status, s.active_lower, s.active_upper,
+                                 s.foot_err, s.iters, wcqp_tick::TickDev{}, smem, blk, 0, true, nullptr, nullptr, &m);
+        wcqp::wave_lds_fence();
+    }
+}
+
 }  // namespace
 
 namespace wcqp_ik {
+
+int ik4_launch_plan(const IkDeviceParams* d_prm, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways,
+                    const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream) {
+    if (!d_prm || !d_recs || batch < 1 || n_steps < 1 || ways < 1 || c.N >= 4 * wcqp_mpc::kLanesPerInstance) return WCQP_E_INVALID;
+    const int groups = (batch + 3) / 4;
+    hipLaunchKernelGGL(qp_plan_kernel, dim3((unsigned)(groups * ways)), dim3(64), 0, stream, d_prm, batch, d_recs, n_steps, ways, groups, c);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
 
 int ik4_launch_pair(const IkDeviceParams* d_prm, int batch,
                     const double* JL, const double* JR, const double* JN, const double* JC,

@@ -396,6 +396,9 @@ int ik4_launch_pair(const IkDeviceParams* d_prm, int batch,
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_tick::TickDev* td_dev,
                     const double* JL, const double* JR, const double* JN, const double* JC,
                     unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream);
+// a plan of steps in ONE launch (wcqp_qp_plan_*): d_recs = the records in device memory
+int ik4_launch_plan(const IkDeviceParams* d_prm, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways,
+                    const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream);
 // the MPC chain of tick t alone: primes the skewed tick after an upload
 int ik4_launch_tick_prime(const wcqp_tick::TickDev& td, int t, hipStream_t stream);
 }  // namespace wcqp_ik
