@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--step-graph", action="store_true", help="qp workload: replay ONE hipGraph that holds the timed steps as P parallel chains (one per "
                     "pipeline) instead of enqueueing them launch by launch.  Measured and left off: 8.9-9.2 us per step against 8.5-9.1 in "
                     "the driver's 20-step form, 8.9 against 7.0 at 200 steps (profiles/r03_step_graph_ab.txt)")
+    ap.add_argument("--resident-pass", action="store_true", help="plan mode: also time the dominant kernel re-reading ONE input set (frac_resident_inputs).  Off by "
+                    "default: every qp_plan_kernel launch of a run then walks through the same number of cold records, so that rocprofv3's "
+                    "average duration and the PMC bytes per launch of that kernel are the numbers of the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     args = ap.parse_args()
@@ -151,11 +154,13 @@ def main():
     base = {k: up(mb[k]) for k in ("x0", "ref", "u_prev", "hull_A", "hull_b")}
     base["hull_nc"] = up(mb["hull_nc"])
     base.update({k: up(ib[k]) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")})
-    # K input sets in distinct HBM allocations, visited round-robin, so that every launch reads COLD inputs: one set is
+    # K input sets in distinct HBM allocations, visited round-robin, so that every step reads COLD inputs: one set is
     # 6.1 KB x B (25 MB at 4096 robots) and would otherwise sit in the 256 MiB Infinity Cache from the previous step.
     # Set k is the same batch rotated by k B / K instances: same work per launch, different bytes at every address.
     set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
-    K = args.input_sets if args.input_sets > 0 else int(min(32, max(2, -(-(320 << 20) // set_bytes))))
+    # (> 1 GiB in total: with 320 MB - 14 sets at 4096 robots - the PMC passes of round 3 showed the one-launch plan getting 31 % of
+    # its input bytes from the 256 MiB Infinity Cache, HBM traffic 0.69 x the algorithmic bytes; launch by launch it was 1.04 x)
+    K = args.input_sets if args.input_sets > 0 else int(min(64, max(2, -(-(1 << 30) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
     use_plan = (args.plan_ways > 0 and not (args.exchange and dist is not None) and args.streams in (0, 1) and args.ik_jac == "mixed"
                 and NH < 64 and not args.step_graph)
@@ -432,8 +437,9 @@ def main():
             ms = e0.elapsed_time(e1)
             pl.close()
             return ms / n
-        n_plan = max(24, 2 * K, args.steps)
-        plan_ms, plan_ms_res = plan_pass(True, n_plan), plan_pass(False, n_plan)
+        n_plan = args.steps                       # the timed launch's own length: rocprofv3's average over the run's launches of this kernel is then THIS number
+        plan_ms = plan_pass(True, n_plan)
+        plan_ms_res = plan_pass(False, n_plan) if args.resident_pass else None
     pair_mode = plan is None and recs is not None and not two_streams and args.ik_jac != "general"
     pair_ms = pair_ms_res = None
     if pair_mode:
@@ -477,15 +483,15 @@ def main():
         # per robot-tick) - or the IK kernel where the two calls are separate launches
         "roofline": ({
             # the dominant kernel IS the timed region: one launch that walks through the steps.  achieved = algorithmic bytes of
-            # a step (6296 B per robot-tick) x steps per launch / launch duration (events, a pass of its own with
-            # max(24, 2 K, steps) records; rocprofv3's average duration of qp_plan_kernel / its records is the same number)
+            # a step (6296 B per robot-tick) x steps per launch / launch duration (events, a pass of its own over
+            # `steps` records like the timed launch: rocprofv3's average duration of qp_plan_kernel for this command is avg_launch_ms)
             "bound": "hbm", "kernel": "qp_plan_kernel",
             "achieved": (IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": plan_ms * n_plan, "steps_per_launch": n_plan, "avg_ms_per_step": plan_ms,
             "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B * n_plan,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (> the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6),
-            "frac_resident_inputs": (IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms_per_step_resident_inputs": plan_ms_res,
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total, 4 x the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6, K * set_bytes / 1e9),
+            "frac_resident_inputs": ((IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS) if plan_ms_res else None, "avg_ms_per_step_resident_inputs": plan_ms_res,
             "timed_region": {"achieved": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9,
                              "frac": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
         } if plan is not None else {
@@ -493,7 +499,7 @@ def main():
             "achieved": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": pair_ms, "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (> the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6),
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total, 4 x the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6, K * set_bytes / 1e9),
             "frac_resident_inputs": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": pair_ms_res,
             # `frac` prices ONE launch running alone (back-to-back launches of the kernel on one stream: what `rocprofv3 --stats`
             # reports for a --pipelines 1 run); with P batches in flight the launches overlap, each takes longer, and the
@@ -504,7 +510,7 @@ def main():
             "bound": "hbm", "kernel": ik_kernel,
             "achieved": ik_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ik_gbs / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": ik_ms, "algorithmic_bytes_per_launch": IK_BYTES_PER_QP * B,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (> the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6),
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total, 4 x the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6, K * set_bytes / 1e9),
             "frac_resident_inputs": IK_BYTES_PER_QP * B / (ik_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": ik_ms_res,
         }),
         "kernels": {
