@@ -8,5 +8,10 @@ int main(void) {
     printf(" %zu %zu %zu %zu %zu %zu %zu", offsetof(wcqp_qp_step, x0), offsetof(wcqp_qp_step, ref_len), offsetof(wcqp_qp_step, u_prev),
            offsetof(wcqp_qp_step, hull_nc), offsetof(wcqp_qp_step, mpc_stream), offsetof(wcqp_qp_step, J_left), offsetof(wcqp_qp_step, ik_stream));
     printf("\n");
+    printf("wcqp_tick_params %zu", sizeof(wcqp_tick_params));
+    printf(" %zu %zu %zu %zu %zu %zu %zu %zu", offsetof(wcqp_tick_params, seed), offsetof(wcqp_tick_params, mpc), offsetof(wcqp_tick_params, ik),
+           offsetof(wcqp_tick_params, ik_cold_start_only), offsetof(wcqp_tick_params, kin), offsetof(wcqp_tick_params, foot_rect),
+           offsetof(wcqp_tick_params, kin_handoff), offsetof(wcqp_tick_params, ticks_per_launch));
+    printf("\n");
     return 0;
 }

@@ -111,7 +111,71 @@ def test_qp_step_record_layout_matches_the_header(tmp_path):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "abi_layout"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "abi_layout.c"), "-o", str(exe)])
-    out = subprocess.check_output([str(exe)], text=True).split()
+    lines = [ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines()]
+    out = lines[0]
     S = wca.capi.QpStep
     mine = [C.sizeof(S)] + [getattr(S, f).offset for f in ("x0", "ref_len", "u_prev", "hull_nc", "mpc_stream", "J_left", "ik_stream")]
     assert out[0] == "wcqp_qp_step" and [int(x) for x in out[1:]] == mine
+    # wcqp_tick_params grew this round (kin_handoff, ticks_per_launch): the ctypes mirror follows the header field for field
+    out = lines[1]
+    T = wca.capi.TickParams
+    mine = [C.sizeof(T)] + [getattr(T, f).offset for f in ("seed", "mpc", "ik", "ik_cold_start_only", "kin", "foot_rect", "kin_handoff", "ticks_per_launch")]
+    assert out[0] == "wcqp_tick_params" and [int(x) for x in out[1:]] == mine
+
+
+def test_source_hash_follows_the_kernel_sources(wca, tmp_path, monkeypatch):
+    """profiles/traffic.json is stamped with capi.source_hash(); bench.py quotes it only while the hash is the current one."""
+    h = wca.capi.source_hash()
+    assert len(h) == 64 and h == wca.capi.source_hash()
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tj = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert set(tj["per_batch"]) == {"4096", "65536"} and len(tj["csrc_sha256"]) == 64
+    for B in ("4096", "65536"):
+        assert 0.95 < tj["per_batch"][B]["plan_ratio"] < 1.15          # no wasted traffic in the committed measurement
+
+
+def test_bench_gpus_n_starts_ranks_and_fails_with_them(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts two ranks before touching the GPU; on this GPU-less host both ranks
+    refuse (there is no CPU path) and the parent's exit code says so - it never reports a 1-GPU number as the 2-GPU point."""
+    import subprocess
+    import sys
+    import walking_controllers_amd as wca
+    if wca.device_count() > 0:
+        pytest.skip("GPU present (the GPU suite runs the real thing)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "rank exit codes" in (r.stderr + r.stdout) and "{" not in r.stdout
+    # and a launcher environment that disagrees with --gpus is refused before any work
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_compact_jacobian_layout_of_the_icub_shaped_tree(wca):
+    """The tick's compact kinematics -> IK hand-off (csrc/tick_device.h: compact_offset): one record per joint - 4 doubles for
+    a joint on no frame path (CoM column + pad), 6 on the neck's, 10 on a foot's - derived from the tree's path masks.  Restated
+    here for the iCub-shaped tree: legs and torso branch at the root link, so the masks are disjoint and a robot's block is 180
+    doubles (1440 B) against the 558 of four dense Jacobians."""
+    m = wca.synth.icub_like_model()
+    parent = list(m["parent"])
+    def path(j):
+        out = 0
+        while j >= 0:
+            out |= 1 << j; j = parent[j]
+        return out
+    mL, mR, mN = (path(int(j)) for j in m["frame_joint"])
+    assert mL & mR == 0 and mL & mN == 0 and mR & mN == 0
+    assert [bin(x).count("1") for x in (mL, mR, mN)] == [6, 6, 3]
+    off, end = [], 0
+    for c in range(23):
+        below = (1 << c) - 1
+        off.append(4 * c + 6 * bin((mL | mR) & below).count("1") + 2 * bin(mN & below).count("1"))
+        end = off[-1] + (10 if ((mL | mR) >> c) & 1 else (6 if (mN >> c) & 1 else 4))
+    assert off == sorted(off) and all(o % 2 == 0 for o in off) and end == 170          # + 9 (+1) doubles of p_frame - p_base = 180
+    # depth-first numbering: every subtree is an index range (what the prefix-sum subtree moments of the kernels rely on)
+    for j in range(23):
+        desc = [k for k in range(23) if (path(k) >> j) & 1]
+        assert desc == list(range(j, j + len(desc)))
