@@ -13,25 +13,29 @@ instance cold-started.  Inputs are resident in HBM before the timed region start
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Consecutive steps are independent batches (cold start: nothing is carried from one step to the next) and at the
-BASELINE batch a launch is one wave per SIMD that spends half its life waiting for its inputs, so step i goes to
-pipeline i % 3, each pipeline with its own streams and output buffers, and the input loads of one batch run under the
-arithmetic of the previous one (`--pipelines 1` for strictly one batch at a time).  The timed steps are handed to the
-library in one host call (`wcqp_qp_enqueue_steps`), which makes the MPC and the IK of a step ONE launch.
+Consecutive steps are independent batches (cold start: nothing is carried from one step to the next), so a step does not
+have to be a launch: the K timed steps are handed to the library once (`wcqp_qp_plan_create`) and enqueued as ONE launch
+(`wcqp_qp_plan_enqueue`) in which a wavefront owns four robots and walks through the steps on its own - the MPC of a step on
+the IK's lanes, under its Jacobian loads - with `--plan-ways` wavefronts per robot group (way w takes steps w, w + ways, ...;
+each way writes its own output buffers).  `--plan-ways 0` is the round-2 form: one launch per step (`qp_pair_kernel`), step i
+on pipeline i % 3 (own stream, own outputs), all handed over in one `wcqp_qp_enqueue_steps` call.
+Every step reads cold inputs (input sets > 1 GiB in total, visited round-robin) and the outputs of every way's last batch
+are compared with the committed golden vectors after the timed region (`solved.golden_*`).
 Timed region: barrier + torch.cuda.synchronize() -> K steps -> every stream's completion event (hipEventSynchronize),
 MAX over ranks; the device-wide synchronize follows the clock (`ms_per_step_incl_device_sync` keeps it inside: on this
-ROCm stack that call costs the host 55-75 us with the device already idle, a fifth of a 20-step region).
+ROCm stack that call costs the host 20-75 us with the device already idle, a fifth of a 20-step region).
 
 Instances are independent, so ranks shard the batch with no data-path collective
 (`scaling: weak`, fixed per-GPU batch); `--exchange` adds the RCCL scatter of inputs from
 rank 0 and gather of solutions to every step and reports that rate too.
 
 The JSON line carries
-  roofline      HBM roofline of the dominant kernel - the one-launch step `qp_pair_kernel` (IK and MPC workgroups in one grid):
-                algorithmic bytes per launch (6296 B per robot-tick = 5240 B/IK-QP + 1056 B/MPC-QP, SURVEY.md §8d, x batch) / its
-                average launch duration, measured with HIP events on the launch stream in a pass of its own after the timed
-                steps (back-to-back launches of that kernel alone, cold and resident inputs); `kernels` keeps the IK and
-                the MPC kernel alone;
+  roofline      HBM roofline of the dominant kernel - the timed launch itself, `qp_plan_kernel`: algorithmic bytes per launch
+                (6296 B per robot-tick = 5240 B/IK-QP + 1056 B/MPC-QP, SURVEY.md §8d, x batch x steps) / the duration of a launch
+                over `steps` cold records, measured with HIP events on the launch stream in a pass of its own after the timed
+                region (rocprofv3's average duration of that kernel for the same command is `avg_launch_ms`); `traffic` = HBM
+                bytes per step from the PMC passes (profiles/traffic.json, quoted only while the kernel sources are the ones
+                it was measured on); `kernels` keeps the stand-alone IK and MPC kernels (`--plan-ways 0`: `qp_pair_kernel`);
   cpu_baseline  oracle/wc_oracle.c (OSQP-algorithm restatement for the MPC, dense dual
                 active set for the IK) timed on this box's host cores on a bounded sample.
 """

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define WCQP_VERSION 300
+#define WCQP_VERSION 301
 
 /* return codes */
 #define WCQP_OK              0
@@ -414,6 +414,16 @@ typedef struct wcqp_tick_params {
      * 0 -> all the ticks of a wcqp_tick_run call in one launch; k > 0: at most k per launch; 1 = one launch per tick (what
      * `use_graph` then replays from a hipGraph of 8 ticks).  Same results whatever the value. */
     int32_t ticks_per_launch;
+    /* > 0: keep, for the first logger_ticks ticks, the row WalkingModule hands its logger per tick (WM/src/WalkingModule.cpp:800-810;
+     * the 53 values behind "record" of the column list :1231-1250), per robot: wcqp_tick_outputs.logger.  Columns:
+     *   0-1 dcm (measured)   2-3 dcm_des   4-5 dcm_des_d (finite difference of the uploaded reference: the planner's DCM velocity is
+     *   not an input of this pipeline)   6-7 zmp (measured = the previous command)   8-9 zmp_des (the MPC's u0)   10-12 com (measured:
+     *   the kinematics' CoM with use_kinematics, else the plant's)   13-14 com_des   15-16 com_des_d   17-19 lf position   20-22 lf
+     *   roll pitch yaw (iDynTree::Rotation::asRPY)   23-28 rf   29-34 lf_des   35-40 rf_des   41-46 lf_err   47-52 rf_err (the IK's
+     *   getLeftFootError / getRightFootError; with kinematics in the tick the dense Jacobians they are formed with do not exist and
+     *   the twelve - residuals of equality constraints, O(1e-15) in the reference too - are logged as zeros).
+     * Runs a logging build of the tick kernel (the default IK kernel only); a debugging aid like the reference's dumpData. */
+    int32_t logger_ticks;
 } wcqp_tick_params;
 
 typedef struct wcqp_tick_inputs {   /* HOST pointers, copied at upload */
@@ -439,6 +449,7 @@ typedef struct wcqp_tick_outputs {  /* HOST pointers, any may be NULL */
                                               dq = 0 from then on and every further tick counts                      */
     int64_t* hot_try; int64_t* hot_hit;    /* [B] ticks on which the previous active set was tried / accepted (IK hot start) */
     int32_t* tick;              /* ticks executed so far                                       */
+    double* logger;             /* [logger_ticks][B][53] logger rows (wcqp_tick_params.logger_ticks)   */
 } wcqp_tick_outputs;
 
 typedef struct wcqp_tick_s* wcqp_tick_t;

@@ -84,7 +84,7 @@ def contact_code(t: int, phase0: np.ndarray, p: TickParams) -> np.ndarray:
 
 
 def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, ik_form: str = "qpoases",
-              kin_model: dict | None = None, foot_rect=None, splices: dict | None = None):
+              kin_model: dict | None = None, foot_rect=None, splices: dict | None = None, logger_ticks: int = 0):
     """data: the arrays of walking-controllers_amd/synth.py::synth_tick_batch (or synth_walk_batch with
     `kin_model`).  Returns the per-tick logs u0[T][B][2], dq[T][B][23] and the final states.
 
@@ -99,7 +99,10 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
     `tick` runs, stages [from_tick, from_tick + n) of every instance's DCM reference are replaced by a newly planned tail
     (the reference splices its deques at a merge point 20 ticks ahead; `resetTrajectory` is raised for that one tick and
     makes MPCSolver::setGradient rebuild the gradient instead of shifting it, MPCSolver.cpp:188-239 - with the gradient always
-    evaluated from the current window, as here, that flag changes nothing)."""
+    evaluated from the current window, as here, that flag changes nothing).
+
+    logger_ticks > 0: also returns `logger` [logger_ticks][B][53], the row WalkingModule hands its logger per tick
+    (WM/src/WalkingModule.cpp:800-810, columns :1231-1250; include/wcqp.h: wcqp_tick_params.logger_ticks says which is which)."""
     if splices:
         data = dict(data)
         data["ref_traj"] = np.array(data["ref_traj"], copy=True)
@@ -121,6 +124,11 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
     hull_cur = [None] * B; hull_code = -np.ones(B, np.int64)
     J_now = [None] * B
     active_log = []
+    logger = np.zeros((logger_ticks, B, 53))
+
+    def rpy(R9):
+        R = np.asarray(R9).reshape(3, 3)         # iDynTree::Rotation::asRPY (upstream)
+        return np.array([np.arctan2(R[2, 1], R[2, 2]), np.arcsin(np.clip(-R[2, 0], -1.0, 1.0)), np.arctan2(R[1, 0], R[0, 0])])
     for t in range(n_ticks):
         if splices and t in splices:
             frm, tail = splices[t]
@@ -164,6 +172,11 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
         v_star = p.k_com * (c_ref - com) - p.k_zmp * (u0 - zmp_meas) + v_ref
         p_star = p_star + 0.5 * p.dT * (v_star + v_star_prev); v_star_prev = v_star
         dq = np.zeros((B, 23))
+        if t < logger_ticks:
+            logger[t, :, 0:2] = dcm; logger[t, :, 2:4] = r_t
+            logger[t, :, 4:6] = (data["ref_traj"][:, t + 1, :] - r_t) / p.dT
+            logger[t, :, 6:8] = zmp_meas; logger[t, :, 8:10] = u0
+            logger[t, :, 13:15] = p_star; logger[t, :, 15:17] = v_star
         for i in range(B):
             s = state_now[i].copy()
             if use_kin:
@@ -187,13 +200,21 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
             Jsrc = {n: J_now[i][n][None] for n in ("J_left", "J_right", "J_neck", "J_com")} if use_kin else \
                    {n: data[n][i:i + 1] for n in ("J_left", "J_right", "J_neck", "J_com")}
             one = dict(q=q_des[i:i + 1], state=s[None, :], **Jsrc)
+            if t < logger_ticks:
+                L = logger[t, i]
+                L[10:13] = s[66:69]
+                L[17:20] = s[0:3]; L[20:23] = rpy(s[3:12]); L[23:26] = s[12:15]; L[26:29] = rpy(s[15:24])
+                L[29:32] = s[24:27]; L[32:35] = rpy(s[27:36]); L[35:38] = s[36:39]; L[38:41] = rpy(s[39:48])
             if ik_fail[i] > 0:
                 # a robot whose IK failed once is stopped: updateModule returns false and the module closes
                 # (WalkingModule.cpp:414-416, 723-739); it keeps dq = 0 and every further tick counts as failed
                 ik_fail[i] += 1
                 continue
             try:
-                dq[i] = qs.ik_exact(ik_params, qs.ik_inputs_from_batch(one, 0), ik_form)["dq"]
+                res_ik = qs.ik_exact(ik_params, qs.ik_inputs_from_batch(one, 0), ik_form)
+                dq[i] = res_ik["dq"]
+                if t < logger_ticks:
+                    logger[t, i, 41:47] = res_ik["foot_err_left"]; logger[t, i, 47:53] = res_ik["foot_err_right"]
             except qs.QPOracleError:
                 ik_fail[i] += 1
         q_des = q_des + 0.5 * p.dT * (dq + dq_prev); dq_prev = dq          # WalkingModule.cpp:741-744
@@ -203,4 +224,4 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
         dcm = c.a * dcm + c.b * u0 + p.noise * w
         zmp_meas = u0.copy(); u_prev = u0.copy()
         u0_log[t] = u0; dq_log[t] = dq
-    return dict(u0_log=u0_log, dq_log=dq_log, q_des=q_des, dcm=dcm, com=com, mpc_fail=mpc_fail, ik_fail=ik_fail)
+    return dict(u0_log=u0_log, dq_log=dq_log, q_des=q_des, dcm=dcm, com=com, mpc_fail=mpc_fail, ik_fail=ik_fail, logger=logger)

@@ -169,6 +169,41 @@ def test_trajectory_merge_on_the_device(wca, qs, ticks_per_launch):
         pipe.splice_reference(T + N, np.zeros((B, 4, 2)))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kin_mode", [False, True], ids=["constant_jacobians", "fused_kinematics"])
+def test_logger_rows_match_the_cpu_restatement(wca, qs, kin_mode):
+    """SURVEY 8f-4, second half: the row WalkingModule hands its logger per tick (WM/src/WalkingModule.cpp:800-810, the 53 columns
+    of :1231-1250) - measured / desired DCM and ZMP, CoM, desired CoM position / velocity, actual and desired foot poses as
+    position + roll-pitch-yaw, foot errors - kept per robot for the first `logger_ticks` ticks by a logging build of the tick
+    kernel; against oracle/tick_spec.py's rows.  The trajectories are the ones of the product kernel, bit for bit."""
+    from oracle import tick_spec as ts
+    B, T, L = 6, 40, 40
+    p = ts.TickParams()
+    if kin_mode:
+        kin, d = _walk_scenario(wca, B, T)
+        vmax = wca.synth.WALK_VMAX
+        mk = lambda: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
+        ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=vmax.copy(), joint_reg_deg=wca.synth.WALK_POSTURE_DEG.copy()),
+                           kin_model=wca.synth.icub_like_model(), foot_rect=wca.synth.FOOT_RECT, logger_ticks=L)
+    else:
+        kin, d = None, wca.synth.synth_tick_batch(B, T)
+        mk = lambda: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.45)
+        ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=0.45 * np.ones(23)), logger_ticks=L)
+    outs = []
+    for lt in (L, 0):
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), mk(), log_ticks=T, kin=kin, logger_ticks=lt)
+        pipe.upload(d); pipe.run(17); pipe.run(T - 17)
+        outs.append(pipe.download())
+    logged, plain = outs
+    assert np.array_equal(logged["dq_log"], plain["dq_log"]) and np.array_equal(logged["u0_log"], plain["u0_log"])
+    assert "logger" not in plain and logged["logger"].shape == (L, B, 53)
+    assert ref["ik_fail"].sum() == 0 and logged["ik_fail"].sum() == 0
+    err = np.abs(logged["logger"] - ref["logger"])
+    assert err[:, :, :41].max() <= 1e-9, np.unravel_index(err[:, :, :41].argmax(), err[:, :, :41].shape)
+    assert err[:, :, 41:].max() <= 1e-9             # foot errors: residuals of equality rows, O(1e-15) on both sides
+    assert np.abs(ref["logger"][:, :, 20:23]).max() > 1e-3 and np.abs(ref["logger"][:, :, 8:10] - ref["logger"][:, :, 6:8]).max() > 1e-6
+
+
 def _walk_scenario(wca, B, T, first=0):
     """A coherent synthetic robot marching in place (synth_walk_batch): poses from the device kinematics at tick 0."""
     kin = wca.KinModel(wca.synth.icub_like_model())

@@ -122,7 +122,7 @@ class TickParams(C.Structure):
                 ("k_com", C.c_double), ("k_zmp", C.c_double), ("noise", C.c_double), ("seed", C.c_uint64),
                 ("mpc", MpcParams), ("ik", IkParams),
                 ("ik_cold_start_only", C.c_int32), ("use_kinematics", C.c_int32), ("kin", KinParams), ("foot_rect", C.c_double * 8),
-                ("kin_handoff", C.c_int32), ("ticks_per_launch", C.c_int32)]
+                ("kin_handoff", C.c_int32), ("ticks_per_launch", C.c_int32), ("logger_ticks", C.c_int32)]
 
 
 class TickInputs(C.Structure):
@@ -132,7 +132,7 @@ class TickInputs(C.Structure):
 
 
 class TickOutputs(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("u0_log", "dq_log", "q_des", "dcm", "com", "mpc_fail", "ik_fail", "hot_try", "hot_hit", "tick")]
+    _fields_ = [(k, C.c_void_p) for k in ("u0_log", "dq_log", "q_des", "dcm", "com", "mpc_fail", "ik_fail", "hot_try", "hot_hit", "tick", "logger")]
 
 
 _lib: Optional[C.CDLL] = None
@@ -392,17 +392,18 @@ class TickPipeline:
     def __init__(self, batch, max_ticks, mpc: MpcSolver, ik: IkSolver, first=0, log_ticks=0,
                  step_ticks=180, ds_ticks=110, k_com=9.0, k_zmp=3.0, noise=1e-4, seed=99,
                  kin: "Optional[KinModel]" = None, foot_rect=None, ik_hot_start: bool = True, kin_handoff: int = 0,
-                 ticks_per_launch: int = 0):
+                 ticks_per_launch: int = 0, logger_ticks: int = 0):
         """kin: a KinModel -> per-tick kinematics (Jacobians, actual poses and hull rows rebuilt every tick from the
         integrated joint state with the base anchored at the stance foot; upload() then ignores J_* / hull_tab_*)."""
         self.batch, self.max_ticks, self.log_ticks, self.dof = batch, max_ticks, log_ticks, ik.dof
+        self.logger_ticks = int(logger_ticks)
         self.use_kin = kin is not None
         if foot_rect is None:
             from .synth import FOOT_RECT
             foot_rect = FOOT_RECT
         self.params = TickParams(batch, first, max_ticks, log_ticks, step_ticks, ds_ticks, k_com, k_zmp, noise, seed,
                                  mpc.params, ik.params, int(not ik_hot_start), int(self.use_kin), kin.params if kin is not None else KinParams(),
-                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(kin_handoff), int(ticks_per_launch))
+                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(kin_handoff), int(ticks_per_launch), int(logger_ticks))
         self._h = C.c_void_p()
         check(lib().wcqp_tick_create(C.byref(self.params), C.byref(self._h)), "wcqp_tick_create")
         self._keep = None
@@ -445,7 +446,9 @@ class TickPipeline:
         o = dict(u0_log=np.zeros((L, B, 2)), dq_log=np.zeros((L, B, D)), q_des=np.zeros((B, D)), dcm=np.zeros((B, 2)),
                  com=np.zeros((B, 2)), mpc_fail=np.zeros(B, np.int64), ik_fail=np.zeros(B, np.int64),
                  hot_try=np.zeros(B, np.int64), hot_hit=np.zeros(B, np.int64), tick=np.zeros(1, np.int32))
-        outs = TickOutputs(**{k: o[k].ctypes.data for k, _ in TickOutputs._fields_})
+        if self.logger_ticks > 0:
+            o["logger"] = np.zeros((self.logger_ticks, B, 53))
+        outs = TickOutputs(**{k: (o[k].ctypes.data if k in o else None) for k, _ in TickOutputs._fields_})
         check(lib().wcqp_tick_download(self._h, C.byref(outs)), "wcqp_tick_download")
         o["tick"] = int(o["tick"][0])
         return o

@@ -122,7 +122,9 @@ struct MpcPairArgs {
 // of the IK's and its arithmetic running while the Jacobians are in flight (what the tick kernel does with the MPC of the next tick).
 // JSRC: where the Jacobians come from - 0 the four dense arrays of the ABI, 1 the compact per-joint records of the tick's
 // kinematics kernel (tick_device.h), 2 the kinematics phase of this kernel itself (no hand-off through memory at all)
-template <bool TICK, int JSRC = 0, bool PAIR = false>
+// LOG (tick kernel, wcqp_tick_params.logger_ticks > 0): also writes the reference's logger row of every robot-tick; a kernel
+// of its own, so that the product kernels carry none of it
+template <bool TICK, int JSRC = 0, bool PAIR = false, bool LOG = false>
 __device__ __forceinline__
 void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -214,7 +216,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0, g_ok = 1.0, g_sw = 0.0, g_h0 = 0.0;
         auto load_handoff = [&]() {
             // hand-off of MPC(t): desired CoM position / velocity (WalkingModule.cpp:686-695), the plant's CoM, did the MPC end usable
-            const double* hd = td.hand + ((size_t)(tick_now & 1) * td.batch + inst) * 10;
+            const double* hd = td.hand + ((size_t)(tick_now & 1) * td.batch + inst) * wcqp_tick::kHandLen;
             const int ja = j & 1;
             g_pstar = hd[ja]; g_vel = hd[2 + ja]; g_com = hd[4 + ja]; g_ok = hd[8];
             g_sw = td.swing_twist[inst * 6 + (j < 6 ? j : 0)];
@@ -581,6 +583,33 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         }
     }
     wcqp::wave_lds_fence();
+    if constexpr (LOG) {
+        // the logger row of this robot-tick (WM/src/WalkingModule.cpp:800-810; columns :1231-1250): measured / desired DCM, desired
+        // DCM velocity, measured / desired ZMP, measured CoM, desired CoM position / velocity, actual and desired foot poses
+        // (position + roll-pitch-yaw), foot errors (written with the IK's result below)
+        if (tick_now < td.logger_ticks && live) {
+            double* row = td.log_rows + ((size_t)tick_now * td.batch + inst) * wcqp_tick::kLoggerCols;
+            if (j < 2) {
+                const double* hd = td.hand + ((size_t)(tick_now & 1) * td.batch + inst) * wcqp_tick::kHandLen;
+                const double r0 = td.ref_traj[((size_t)inst * td.traj_len + tick_now) * 2 + j];
+                const double r1 = td.ref_traj[((size_t)inst * td.traj_len + tick_now + 1) * 2 + j];
+                row[j] = hd[6 + j]; row[2 + j] = r0; row[4 + j] = (r1 - r0) / td.dT;        // the planner's DCM velocity: finite difference of the reference
+                row[6 + j] = hd[10 + j]; row[8 + j] = hd[12 + j];
+                row[13 + j] = hd[j]; row[15 + j] = hd[2 + j];
+            }
+            if (j < 3) {
+                row[10 + j] = st[66 + j];
+                row[17 + j] = st[j]; row[23 + j] = st[12 + j]; row[29 + j] = st[24 + j]; row[35 + j] = st[36 + j];
+            }
+            if (j < 4) {
+                // iDynTree::Rotation::asRPY (upstream): roll = atan2(R21, R22), pitch = asin(-R20), yaw = atan2(R10, R00)
+                const double* R = st + (j == 0 ? 3 : (j == 1 ? 15 : (j == 2 ? 27 : 39)));
+                double* o = row + (j == 0 ? 20 : (j == 1 ? 26 : (j == 2 ? 32 : 38)));
+                const double s_ = fmin(1.0, fmax(-1.0, -R[6]));
+                o[0] = atan2(R[7], R[8]); o[1] = asin(s_); o[2] = atan2(R[3], R[0]);
+            }
+        }
+    }
     if constexpr (COMPACT) {
         auto unpack = [&](const double2 (&r)[5], int kind, double (&a)[NROWS_IN]) {
             const double x[6] = {r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, r[4].x};
@@ -1431,7 +1460,15 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 jv = uv[rr];
             }
             ferr_out[inst * 12 + j] = u_mine - jv;
+            if constexpr (LOG) {
+                if (tick_now < td.logger_ticks) td.log_rows[((size_t)tick_now * td.batch + inst) * wcqp_tick::kLoggerCols + 41 + j] = u_mine - jv;
+            }
         }
+    }
+    if constexpr (LOG && JSRC != 0) {
+        // fused / compact kinematics: the dense Jacobians the residual is formed with do not exist; the twelve foot rows are equality
+        // constraints of the QP and hold to rounding (the reference's own values are O(1e-15)): logged as zeros
+        if (tick_now < td.logger_ticks && live && j < 12) td.log_rows[((size_t)tick_now * td.batch + inst) * wcqp_tick::kLoggerCols + 41 + j] = 0.0;
     }
 }
 
@@ -1442,7 +1479,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 // memory for tick t + 1 (joint state, hand-off record, previous active set, live hull rows) is written and read by the
 // same wave, ordered by a workgroup-scope fence per tick.  No per-tick launch, no ramp-up / tail per tick, and a wave
 // whose robots walk a long active set on one tick catches up on the next instead of holding the whole launch.
-template <bool TICK, int JSRC>
+template <bool TICK, int JSRC, bool LOG = false>
 __global__ __launch_bounds__(64, WCQP_IK4_WAVES)
 void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -1470,8 +1507,8 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll 1
         for (int k = 0; k < n_inner; ++k) {
             __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop (its registers are all spoken for)
-            ik4_body<TICK, JSRC>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
-                                 (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains);
+            ik4_body<TICK, JSRC, false, LOG>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
+                                             (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains);
             // tick t + 1 of this wave reads what tick t wrote (other lanes of the same wave): visible before it starts
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -1605,13 +1642,28 @@ int ik4_launch(const IkDeviceParams* d_prm, int batch,
 
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_tick::TickDev* td_dev,
                     const double* JL, const double* JR, const double* JN, const double* JC,
-                    unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream) {
+                    unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream, double* log_ferr) {
     if (n_inner < 1 || (n_inner > 1 && td.kin_mode && !td.kin_fused)) return WCQP_E_INVALID;      // kinematics in a launch of their own: the Jacobians of tick t + 1 come from another launch
     if (!d_prm || !td_dev || !td.skew || !td.mst || !td.hand || !td.live_A || !td.live_b || !td.live_nc || !td.sel_built) return WCQP_E_INVALID;
     if (td.compact && (!td.jcomp || td.cstride < 1)) return WCQP_E_INVALID;
     if (td.kin_fused && (!td.kin_tab || !td.kin_mode || td.kin_rounds < 0 || td.kin_rounds > 3 || td.horizon >= wcqp_tick::kGainsLdsStages)) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((td.batch + 3) / 4);
     const IkDeviceParams* prm = static_cast<const IkDeviceParams*>(d_prm);
+    if (td.logger_ticks > 0) {
+        // the logging kernels (a debugging aid like the reference's dumpData): dense Jacobians also produce the foot errors
+        if (!td.log_rows) return WCQP_E_INVALID;
+        if (td.kin_fused)
+            hipLaunchKernelGGL((ik4_kernel<true, 2, true>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
+                               JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
+        else if (td.compact)
+            hipLaunchKernelGGL((ik4_kernel<true, 1, true>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
+                               JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
+        else
+            hipLaunchKernelGGL((ik4_kernel<true, 0, true>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
+                               JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, log_ferr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
+        WCQP_HIP_TRY(hipGetLastError());
+        return WCQP_OK;
+    }
     if (td.kin_fused)
         hipLaunchKernelGGL((ik4_kernel<true, 2>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
                            JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);

@@ -395,7 +395,7 @@ int ik4_launch_pair(const IkDeviceParams* d_prm, int batch,
 // passed as a kernel argument, the copy's is not read)
 int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_tick::TickDev* td_dev,
                     const double* JL, const double* JR, const double* JN, const double* JC,
-                    unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream);
+                    unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream, double* log_ferr = nullptr);
 // a plan of steps in ONE launch (wcqp_qp_plan_*): d_recs = the records in device memory
 int ik4_launch_plan(const IkDeviceParams* d_prm, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways,
                     const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream);

@@ -67,6 +67,7 @@ struct wcqp_tick_s {
     hipStream_t graph_stream = nullptr;
     bool uploaded = false;
     int ticks_enqueued = 0;  // since the last upload; its parity is the `phase` of the next tick
+    double* log_ferr = nullptr;   // logger rows with dense Jacobians: where the IK kernel forms the foot errors
     bool fused = false;      // glue + post inside the 16-lane IK kernel: 2 launches per tick instead of 4
     bool base_elim = false;  // the fused kernel is the base-eliminated one (ik4.hip)
     wcqp_kin_t kin = nullptr;     // use_kinematics: Jacobians, actual poses and hull rows are rebuilt every tick
@@ -103,7 +104,7 @@ int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s, int n_inner = 1, int 
     // base-eliminated IK kernel: IK + post step of this tick and MPC + glue + plant of the NEXT one in ONE launch (skewed tick)
     if (h->fused && h->base_elim)
         return wcqp_ik::ik4_launch_tick(wcqp::ik_device_params(h->ik), d, h->d_dev, h->J_left, h->J_right, h->J_neck, h->J_com,
-                                        h->ik_lo, h->ik_up, n_inner, skip_last_mpc, s);
+                                        h->ik_lo, h->ik_up, n_inner, skip_last_mpc, s, h->log_ferr);
     int rc = wcqp::mpc_enqueue(h->mpc, B, d.dcm, d.ref_traj, N + 1, d.traj_len, d.tick2 + d.phase, d.u_prev,
                                d.hull_tab_A, d.hull_tab_b, d.hull_tab_nc, d.hull_sets, d.hull_sets > 1 ? d.sel : nullptr,
                                d.u0, d.mpc_status, h->mpc_active, h->mpc_margin, s);
@@ -154,7 +155,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     // the tick's Jacobians are MIXED free-floating ones (uploaded or from wcqp_kin_*): an instance that is not comes
     // back WCQP_STATUS_STRUCTURE and counts as an IK failure
     h->d.hot_start = params->ik_cold_start_only ? 0 : 1;
-    if (params->ticks_per_launch < 0) { wcqp_tick_destroy(h); return WCQP_E_INVALID; }
+    if (params->ticks_per_launch < 0 || params->logger_ticks < 0) { wcqp_tick_destroy(h); return WCQP_E_INVALID; }
     h->base_elim = h->fused && params->ik.algorithm != WCQP_IK_ALG_NULLSPACE_16L &&
                    params->ik.jacobian_structure != WCQP_IK_JAC_GENERAL && wcqp::ik_fast_ok(h->ik);
     const size_t B = (size_t)params->batch;
@@ -196,8 +197,9 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
                         wcqp::kin_fused_tables(h->kin, ktab, d.kin_up, d.kin_sub_end, d.kin_frame_joint, &d.kin_rounds);
     const bool compact = masks_ok && !fusedk && params->kin_handoff != WCQP_KIN_HANDOFF_DENSE;
     if (d.skew) {
-        A_(d.mst, B * 16); A_(d.hand, 2 * B * 10); A_(d.live_A, B * 16); A_(d.live_b, B * 8); A_(d.live_nc, B); A_(d.sel_built, B);
+        A_(d.mst, B * 16); A_(d.hand, 2 * B * kHandLen); A_(d.live_A, B * 16); A_(d.live_b, B * 8); A_(d.live_nc, B); A_(d.sel_built, B);
         if (compact) A_(jcomp, B * (size_t)cstride);
+        if (params->logger_ticks > 0) { A_(d.log_rows, (size_t)params->logger_ticks * B * kLoggerCols); A_(h->log_ferr, B * 12); d.logger_ticks = params->logger_ticks; }
         if (fusedk) {
             double* kt = nullptr;
             A_(kt, ktab.size());
@@ -387,6 +389,10 @@ int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
 #define DN_(dst, src, n) if (dst) WCQP_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
     DN_(out->u0_log, d.u0_log, (size_t)d.log_ticks * B * 16); DN_(out->dq_log, d.dq_log, (size_t)d.log_ticks * B * kDof * 8);
     DN_(out->q_des, d.q_des, B * kDof * 8);
+    if (out->logger) {
+        if (!d.log_rows) return WCQP_E_UNSUPPORTED;          // logger_ticks = 0, or an IK algorithm without the fused tick kernel
+        WCQP_HIP_TRY(hipMemcpy(out->logger, d.log_rows, (size_t)d.logger_ticks * B * kLoggerCols * 8, hipMemcpyDeviceToHost));
+    }
     if (d.skew) {
         // the state of the MPC chain lives in per-axis records (TickDev::mst): com at [2], dcm at [6]
         if (out->dcm || out->com) {

@@ -50,8 +50,9 @@ struct TickDev {
     int skew;
     double* mst;        // [B][2][8] state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (= measured ZMP), p_star,
                         //           v_star_prev, dcm, spare - one 64-byte record per axis, loaded as four 16-byte pieces
-    double* hand;       // [2][B][10] MPC(t) -> IK(t) at parity t & 1: p_star xy, v_star xy, com(t) xy, dcm(t) xy, mpc_ok, spare
-                        //           (com(t) / dcm(t): the plant state at the START of tick t - what wcqp_tick_download reports)
+    double* hand;       // [2][B][kHandLen] MPC(t) -> IK(t) at parity t & 1: p_star xy, v_star xy, com(t) xy, dcm(t) xy, mpc_ok, spare,
+                        //           measured ZMP(t) xy (= the previous command), u0(t) xy   (com / dcm / ZMP: the plant at the START of
+                        //           tick t; the last six entries feed the logger rows only)
     double* live_A; double* live_b; int* live_nc; int* sel_built;     // one live hull row set per robot ([B][8][2], [B][8], [B])
                         //           and the contact pair it holds: copied from the robot's three-set table on a contact change, so
                         //           that the rows of a tick are loaded from a fixed address, without waiting for the contact pair
@@ -68,7 +69,13 @@ struct TickDev {
     int kin_fused, kin_rounds;
     const double* kin_tab;
     int kin_up[3][24], kin_sub_end[24], kin_frame_joint[3];
+    // ---- logger rows (wcqp_tick_params.logger_ticks): the 53 values WalkingModule hands its logger per tick
+    // (WM/src/WalkingModule.cpp:800-810, column names :1231-1250), kept for the first logger_ticks ticks
+    double* log_rows;   // [logger_ticks][B][kLoggerCols]
+    int logger_ticks;
 };
+constexpr int kHandLen = 14;
+constexpr int kLoggerCols = 53;
 constexpr int kKinTabJoint = 20, kKinTabFrames = 20 * kDof, kKinTabRoot = kKinTabFrames + 36, kKinTabSize = kKinTabRoot + 4;
 constexpr int kGainsLdsStages = 64;        // fused kinematics: the MPC's gain blocks Gr ((N + 1) x 2 x 2, N <= 63) sit in LDS beside the model
 
@@ -292,9 +299,10 @@ __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, lo
         double2* sp = reinterpret_cast<double2*>(d.mst + (inst * 2 + ax) * 8);
         sp[0] = make_double2(c_ref, vr); sp[1] = make_double2(com1, u); sp[2] = make_double2(p_star, v); sp[3] = make_double2(xi1, 0.0);
         // hand-off to the IK of tick t (desired CoM position / velocity, WalkingModule.cpp:686-695) + the plant state at the start of tick t
-        double* hd = d.hand + ((size_t)(t & 1) * d.batch + inst) * 10;
+        double* hd = d.hand + ((size_t)(t & 1) * d.batch + inst) * kHandLen;
         hd[ax] = p_star; hd[2 + ax] = v; hd[4 + ax] = com; hd[6 + ax] = xi;
         if (ax == 0) hd[8] = mpc_ok ? 1.0 : 0.0;
+        hd[10 + ax] = u_prev; hd[12 + ax] = u;
         if (t < d.log_ticks) d.u0_log[((size_t)t * d.batch + inst) * 2 + ax] = u;
     }
 }
