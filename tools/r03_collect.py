@@ -37,8 +37,8 @@ def digest(prefix, kern, units, what):
 
 out = {"note": "rocprofv3 --pmc passes of tools/gpu_r03_profiles.sh (one counter group per run, --kernel-trace only). per_wave_unit: counter totals over all "
                "launches of the run / (workgroups x records or ticks they walked through); SQ_WAVE_CYCLES counts in units of 4 cycles.",
-       # bench.py --steps 28 (K = 14 at that time): 5 launches of 28 records, 1024 robot groups -> 5 x 28 x 1024 wave-records
-       "qp_plan_kernel_b4096": digest("plan_4096", "qp_plan_kernel", 5 * 28 * 1024, "one wave-record = the IK and the MPC of 4 robots of one step"),
+       # bench.py --steps 88: 14 launches of 88 records (timed + the roofline pass: 2 warm + 10 timed ... ), 1024 robot groups -> 5 x 28 x 1024 wave-records
+       "qp_plan_kernel_b4096": digest("plan_4096", "qp_plan_kernel", 14 * 88 * 1024, "one wave-record = the IK and the MPC of 4 robots of one step"),
        # bench.py --workload tick --steps 200 --warmup 24: 224 ticks, 2048 workgroups
        "ik4_tick_kernel_fused_kinematics_b8192": digest("tickkin_8192", "ik4_tick_kernel", 224 * 2048, "one wave-tick = kinematics + MPC(t+1) + IK + post step of 4 robots")}
 json.dump(out, open(os.path.join(P, "r03_pmc_detail.json"), "w"), indent=1)
