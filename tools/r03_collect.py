@@ -14,13 +14,15 @@ shutil.copy(os.path.join(O, "traffic.json"), os.path.join(P, "traffic.json"))
 d = json.load(open(os.path.join(O, "pmc_summary.json")))
 
 
-def digest(prefix, kern, units, what):
-    c = {}
+def digest(prefix, kern, units_per_launch, what, units_total=None):
+    c, launches = {}, 0
     for p in ("p1", "p2", "p3"):
         for k, v in d.get("%s_%s" % (prefix, p), {}).get(kern, {}).items():
             c[k] = v["total"]
+            launches = v["launches"]
     if not c:
         return None
+    units = units_total if units_total else launches * units_per_launch
     waves_x_units = units                       # wave-records / wave-ticks the counters cover
     g = lambda k: c.get(k, 0.0)
     return {"what": what, "wave_units": waves_x_units,
@@ -37,10 +39,10 @@ def digest(prefix, kern, units, what):
 
 out = {"note": "rocprofv3 --pmc passes of tools/gpu_r03_profiles.sh (one counter group per run, --kernel-trace only). per_wave_unit: counter totals over all "
                "launches of the run / (workgroups x records or ticks they walked through); SQ_WAVE_CYCLES counts in units of 4 cycles.",
-       # bench.py --steps 88: 14 launches of 88 records (timed + the roofline pass: 2 warm + 10 timed ... ), 1024 robot groups -> 5 x 28 x 1024 wave-records
-       "qp_plan_kernel_b4096": digest("plan_4096", "qp_plan_kernel", 14 * 88 * 1024, "one wave-record = the IK and the MPC of 4 robots of one step"),
-       # bench.py --workload tick --steps 200 --warmup 24: 224 ticks, 2048 workgroups
-       "ik4_tick_kernel_fused_kinematics_b8192": digest("tickkin_8192", "ik4_tick_kernel", 224 * 2048, "one wave-tick = kinematics + MPC(t+1) + IK + post step of 4 robots")}
+       # bench.py --steps 88: every qp_plan_kernel launch of the run (the timed one and the roofline pass's) walks through 88 records, 1024 robot groups
+       "qp_plan_kernel_b4096": digest("plan_4096", "qp_plan_kernel", 88 * 1024, "one wave-record = the IK and the MPC of 4 robots of one step"),
+       # bench.py --workload tick --steps 200 --warmup 24: 224 ticks in two launches, 2048 workgroups
+       "ik4_tick_kernel_fused_kinematics_b8192": digest("tickkin_8192", "ik4_tick_kernel", None, "one wave-tick = kinematics + MPC(t+1) + IK + post step of 4 robots", units_total=224 * 2048)}
 json.dump(out, open(os.path.join(P, "r03_pmc_detail.json"), "w"), indent=1)
 for k in ("qp_plan_kernel_b4096", "ik4_tick_kernel_fused_kinematics_b8192"):
     if out[k]:
