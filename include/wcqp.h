@@ -361,10 +361,15 @@ int wcqp_kin_jacobians_host(wcqp_kin_t h, int32_t batch, const double* base, con
  *         velocity into the IK pose block (WalkingModule.cpp:686-695); synthetic LIPM plant
  *   IK    joint velocities
  *   post  q <- Integrator(dq) (WalkingModule.cpp:741-744), contact pair of the next tick, tick += 1
- * With the default IK kernel (base elimination) the MPC, the glue, the IK and the post step run in ONE
- * launch per tick; the general 16-lane kernel (algorithm 4) takes two (MPC, IK), an explicit 32-lane / sweep IK
- * algorithm or the CoM-as-cost variant four (stand-alone glue / post kernels).  `use_graph` replays hipGraphs of 8 ticks each (captured
- * ONCE: the tick index lives in device memory), remaining ticks go as plain launches.
+ * With the default IK kernel (base elimination) a tick is ONE kernel - forward kinematics (use_kinematics), the MPC chain, the glue,
+ * the IK and the post step on the 16 lanes a robot's IK runs on - and, the robots of a wavefront depending on no other wavefront's,
+ * a launch walks through ALL the ticks of a wcqp_tick_run call (ticks_per_launch).  The MPC -> ZMP-CoM law -> plant chain does not
+ * depend on the IK, so the tick is SKEWED inside a call: the kernel solves IK(t) and, in the shadow of its loads, the MPC chain of
+ * tick t + 1 (a call starts with the MPC of its first tick alone and its last tick runs no MPC ahead: between calls nothing is
+ * ahead of anything).  Same results as the in-order forms that remain for the other IK algorithms: the general 16-lane kernel
+ * (algorithm 4) takes an MPC launch and an IK launch per tick, an explicit 32-lane / sweep IK algorithm or the CoM-as-cost
+ * variant four (stand-alone glue / post kernels); for those, and with ticks_per_launch = 1, `use_graph` replays hipGraphs of 8
+ * ticks each (captured ONCE: the tick index lives in device memory), remaining ticks go as plain launches.
  * ===================================================================================== */
 #define WCQP_KIN_HANDOFF_FUSED   0
 #define WCQP_KIN_HANDOFF_DENSE   1
@@ -383,11 +388,12 @@ typedef struct wcqp_tick_params {
     /* Per-tick kinematics (SURVEY.md 8f-4 inside the tick, WM/src/WalkingModule.cpp:715, 396-410): when set, every tick
      * first evaluates the forward kinematics of `kin` at the integrated joint positions q_des with the floating base
      * anchored at the stance foot of the current step (world_T_base = desired sole pose x inverse of the sole's pose in
-     * the base frame: WalkingFK::evaluateWorldToBaseTransformation, WM/src/WalkingForwardKinematics.cpp:160-256), writes
-     * the four MIXED Jacobians and the actual foot / neck poses the IK of the tick reads, and rebuilds the
-     * support-polygon rows from the DESIRED foot poses (state0 entries 24..47, `foot_rect`) whenever an instance's
-     * contact pair changes (setConvexHullConstraint, ...PredictiveController.cpp:364-435).  Two launches per tick
-     * (kinematics, solve).  The J_* and hull_tab_* inputs are then ignored (may be NULL). */
+     * the base frame: WalkingFK::evaluateWorldToBaseTransformation, WM/src/WalkingForwardKinematics.cpp:160-256) and gives
+     * the IK of the tick the four MIXED Jacobians and the actual foot / neck poses and CoM (`kin_handoff` says how); the
+     * support-polygon rows of the three contact pairs are built from the DESIRED foot poses (state0 entries 24..47,
+     * `foot_rect`) when those are uploaded, and a tick selects by its contact pair (setConvexHullConstraint,
+     * ...PredictiveController.cpp:364-435, switches rows only when the pair changes).  The J_* and hull_tab_* inputs are
+     * then ignored (may be NULL). */
     /* IK hot start (SQProblem::hotstart, WM/src/WalkingQPInverseKinematics_qpOASES.cpp:312-335): by default every tick
      * first tries the previous tick's active joint-velocity bounds of the robot (added in one step, accepted when all
      * their multipliers are positive) and falls back to the cold active-set walk otherwise; 1 = always cold.
