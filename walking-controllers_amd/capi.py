@@ -455,13 +455,13 @@ class TickPipeline:
 
 
 def source_hash() -> str:
-    """sha256 over the kernel / ABI sources (csrc/*.hip, *.h, *.cpp and include/wcqp.h): what a measurement that is kept in the
-    repository (profiles/traffic.json) is stamped with, so that it is not quoted for kernels that have changed since."""
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp): what a measurement that is kept in the repository
+    (profiles/traffic.json) is stamped with, so that it is not quoted for kernels that have changed since."""
     import glob
     import hashlib
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
-                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(os.path.dirname(_HERE), "include", "wcqp.h")])
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")))
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
