@@ -167,7 +167,7 @@ def main():
     K = args.input_sets if args.input_sets > 0 else int(min(64, max(2, -(-(1 << 30) // set_bytes))))
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
     use_plan = (args.plan_ways > 0 and not (args.exchange and dist is not None) and args.streams in (0, 1) and args.ik_jac == "mixed"
-                and NH < 64 and not args.step_graph)
+                and not args.step_graph)
     if use_plan:
         P = args.pipelines if args.pipelines > 0 else args.plan_ways           # one output buffer set per way
     else:

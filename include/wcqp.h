@@ -295,8 +295,8 @@ int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch,
  * ... (two ways fill both wave slots of every SIMD at the BASELINE batch of 4096).  Records of DIFFERENT ways run
  * concurrently: they must not share output arrays (give each way its own, like the pipelines of separate streams).  Every
  * record needs both parts; the stream fields of the records are ignored (wcqp_qp_plan_enqueue names the stream).
- * WCQP_E_UNSUPPORTED unless the IK handle runs its default kernel with jacobian_structure = WCQP_IK_JAC_MIXED and the MPC
- * horizon is <= 63: use wcqp_qp_enqueue_steps then.  Same results as the single calls, bit for bit.  The arrays the
+ * WCQP_E_UNSUPPORTED unless the IK handle runs its default kernel with jacobian_structure = WCQP_IK_JAC_MIXED: use
+ * wcqp_qp_enqueue_steps then.  Same results as the single calls, bit for bit.  The arrays the
  * records point to must stay valid while the plan is used; the handles must outlive the plan. */
 typedef struct wcqp_qp_plan_s* wcqp_qp_plan_t;
 int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_steps, const wcqp_qp_step* steps, int32_t ways,

@@ -9,13 +9,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import walking_controllers_amd as wca
 
 
-def main(B, ways, R=7):
+def main(B, ways, R=7, horizon=50):
     dev = torch.device("cuda", 0)
-    mpc, ik = wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, jacobian_structure=wca.IK_JAC_MIXED)
+    mpc, ik = wca.MpcSolver(horizon=horizon), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, jacobian_structure=wca.IK_JAC_MIXED)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     sets = []
     for seed in range(R):
-        mb, ib = wca.synth.synth_mpc_batch(B, seed=50 + seed, uprev_sigma=0.03), wca.synth.synth_ik_batch(B, seed=150 + seed)
+        mb, ib = wca.synth.synth_mpc_batch(B, seed=50 + seed, uprev_sigma=0.03, horizon=horizon), wca.synth.synth_ik_batch(B, seed=150 + seed)
         sets.append(({k: t(mb[k]) for k in ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc")},
                      {k: t(ib[k]) for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")}))
 
@@ -65,4 +65,6 @@ def main(B, ways, R=7):
 if __name__ == "__main__":
     for B, ways in ((1, 1), (5, 3), (777, 2), (4096, 2), (4096, 9)):      # ragged batches; more ways than records
         main(B, ways)
+    main(333, 2, R=3, horizon=200)                                         # the shipped horizon: more than one 64-stage pass of the window
+    main(64, 1, R=2, horizon=7)
     print("plan ok")

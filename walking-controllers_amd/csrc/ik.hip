@@ -617,10 +617,9 @@ int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_s
                         wcqp_qp_plan_t* out) {
     if (!mpc || !ik || !out || batch < 1 || n_steps < 1 || !steps || ways < 1) return WCQP_E_INVALID;
     // one launch walks through the records: that is the base-eliminated kernel on Jacobians the caller declares MIXED (no
-    // fall-back launch behind it), with the MPC on the IK's lanes (a horizon of one pass: N <= 63)
+    // fall-back launch behind it), with the MPC on the IK's lanes
     const bool want4 = ik->p.algorithm == WCQP_IK_ALG_BASE_ELIM || ik->p.algorithm == WCQP_IK_ALG_DEFAULT;
     if (!(want4 && ik->hp.fast_ok && ik->p.jacobian_structure == WCQP_IK_JAC_MIXED)) return WCQP_E_UNSUPPORTED;
-    if (wcqp::mpc_horizon(mpc) >= 4 * wcqp_mpc::kLanesPerInstance) return WCQP_E_UNSUPPORTED;
     for (int k = 0; k < n_steps; ++k) {
         const wcqp_qp_step& s = steps[k];
         if (!s.x0 || !s.ref || s.ref_len < 1 || !s.u_prev || !s.hull_A || !s.hull_b || !s.hull_nc || !s.u0 || !s.mpc_status) return WCQP_E_INVALID;

@@ -530,6 +530,8 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             int mst_;
             unsigned mact;
             wcqp_mpc::mpc_row_partial(pm->c, j, mreg.L, ux, uy);
+            if (pm->c.N >= 4 * wcqp_mpc::kLanesPerInstance)          // a horizon beyond one 64-stage pass (the shipped N = 200): the rest of the window, loaded on the spot
+                wcqp_mpc::mpc_row_extra_passes(pm->c, j, reinterpret_cast<const double2*>(pm->ref) + inst * pm->ref_len, pm->ref_len, ux, uy);
             if (j == 0) wcqp_mpc::mpc_row_add_state(pm->c, p_xs, p_up, ux, uy);
             wcqp_mpc::mpc_row_finish(pm->c, j, ux, uy, mreg.nc, mreg.ha.x, mreg.ha.y, mreg.hb, reinterpret_cast<double (*)[4]>(S + OFF_COL), u0x, u0y, mst_, mact, margin);
             if (j == 0 && live) {
@@ -1606,7 +1608,7 @@ namespace wcqp_ik {
 
 int ik4_launch_plan(const IkDeviceParams* d_prm, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways,
                     const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream) {
-    if (!d_prm || !d_recs || batch < 1 || n_steps < 1 || ways < 1 || c.N >= 4 * wcqp_mpc::kLanesPerInstance) return WCQP_E_INVALID;
+    if (!d_prm || !d_recs || batch < 1 || n_steps < 1 || ways < 1) return WCQP_E_INVALID;
     const int groups = (batch + 3) / 4;
     hipLaunchKernelGGL(qp_plan_kernel, dim3((unsigned)(groups * ways)), dim3(64), 0, stream, d_prm, batch, d_recs, n_steps, ways, groups, c);
     WCQP_HIP_TRY(hipGetLastError());
