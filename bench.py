@@ -546,7 +546,7 @@ def main():
             # only while the kernels are the ones the PMC passes ran on (tools/pmc/make_traffic.py stamps the sources' hash)
             if tj.get("csrc_sha256") != wca.capi.source_hash():
                 out["roofline"]["traffic_note"] = "profiles/traffic.json was measured on other kernel sources (re-run tools/pmc/collect.sh + make_traffic.py): not quoted"
-            elif tr:
+            elif tr and NH == 50:                                                   # measured on the BASELINE horizon
                 out["roofline"]["traffic"] = tr.get("plan_hbm_bytes_per_step") if plan is not None else tr.get("pair_hbm_bytes_per_launch" if pair_mode else "ik_hbm_bytes_per_launch")
         except Exception:
             pass
