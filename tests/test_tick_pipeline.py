@@ -99,7 +99,8 @@ def test_tick_pipeline_long_run_is_stable_and_shard_invariant(wca):
 
 
 @pytest.mark.gpu
-def test_tick_run_refuses_to_run_past_the_trajectories(wca):
+@pytest.mark.parametrize("ticks_per_launch", [0, 1, 3], ids=["whole_call_per_launch", "one_tick_per_launch", "three_per_launch"])
+def test_tick_run_refuses_to_run_past_the_trajectories(wca, ticks_per_launch):
     """The per-instance trajectories hold max_ticks + N + 1 stages: enqueueing more ticks than that (in one call or
     over several) must be refused, not read the neighbour's trajectory; odd tick counts exercise the
     phase parity of the two-copy tick index with and without graph replays."""
@@ -109,11 +110,12 @@ def test_tick_run_refuses_to_run_past_the_trajectories(wca):
     ref = wca.TickPipeline(B, T, wca.MpcSolver(), ik(), log_ticks=T)
     ref.upload(d); ref.run(T, use_graph=False)
     want = ref.download()
-    pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik(), log_ticks=T)
+    pipe = wca.TickPipeline(B, T, wca.MpcSolver(), ik(), log_ticks=T, ticks_per_launch=ticks_per_launch)
     pipe.upload(d)
     with pytest.raises(wca.WcqpError):
         pipe.run(T + 1, use_graph=False)
-    pipe.run(3, use_graph=True)          # plain (fewer than a graph's 8 ticks), leaves an odd tick index
+    pipe.run(1, use_graph=True)          # a call of ONE tick: the MPC of its tick alone, then the tick without an MPC ahead
+    pipe.run(2, use_graph=True)          # plain (fewer than a graph's 8 ticks), leaves an odd tick index
     pipe.run(19, use_graph=True)         # one plain tick to an even index, two graph replays, two plain ticks
     pipe.run(8, use_graph=False)
     with pytest.raises(wca.WcqpError):
