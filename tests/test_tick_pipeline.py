@@ -70,6 +70,33 @@ def test_tick_pipeline_matches_cpu_restatement(wca, qs, ik_algorithm):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kin_mode", [False, True], ids=["constant_jacobians", "fused_kinematics"])
+def test_tick_pipeline_in_the_osqp_form(wca, qs, kin_mode):
+    """The tick with the reference's osqp back-end semantics (WalkingQPIK_osqp: joint-limit rows that never bind, the extra
+    k_attFoot on the neck term, the zero-twist rule for the foot in contact - SURVEY Appendix B-13/14/15): the stance foot's
+    twist IS exactly zero in the tick, so the zero-twist branch is the one that runs.  Against oracle/tick_spec.py at 1e-9."""
+    from oracle import tick_spec as ts
+    B, T = 8, 90
+    p = ts.TickParams()
+    if kin_mode:
+        kin, d = _walk_scenario(wca, B, T)
+        extra = dict(joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
+        ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=np.ones(23), joint_reg_deg=wca.synth.WALK_POSTURE_DEG.copy()), ik_form="osqp",
+                           kin_model=wca.synth.icub_like_model(), foot_rect=wca.synth.FOOT_RECT)
+    else:
+        kin, d, extra = None, wca.synth.synth_tick_batch(B, T), {}
+        ref = ts.run_ticks(p, d, T, qs.IKParams(v_max=np.ones(23)), ik_form="osqp")
+    assert ref["ik_fail"].sum() == 0 and ref["mpc_fail"].sum() == 0
+    pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_OSQP, v_max=1.0, **extra), log_ticks=T, kin=kin)
+    pipe.upload(d); pipe.run(T)
+    out = pipe.download()
+    assert out["tick"] == T and out["ik_fail"].sum() == 0 and out["mpc_fail"].sum() == 0
+    assert np.abs(out["u0_log"] - ref["u0_log"]).max() <= 1e-9 and np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8
+    assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9
+    assert np.abs(ref["dq_log"]).max() > 0.05
+
+
+@pytest.mark.gpu
 def test_tick_pipeline_long_run_is_stable_and_shard_invariant(wca):
     """1000 ticks (config 5 length) on 512 robots: no solver failure, DCM stays on its reference,
     and two half-batches reproduce the full batch bit for bit."""
