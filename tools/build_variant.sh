@@ -6,8 +6,8 @@ name=$1; shift
 cd "$(dirname "$0")/../walking-controllers_amd/csrc"
 make -s >/dev/null
 mkdir -p build/diag
-for f in ik ik2 ik3 ik4 kin; do
+for f in ik ik2 ik3 ik4 kin tick; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -DWCQP_DIAG_KERNELS "$@" -x hip -c $f.hip -o build/diag/${f}_$name.o
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/diag/libwcqp_$name.so build/common.cpp.o build/mpc.hip.o build/diag/ik_$name.o build/diag/ik2_$name.o build/diag/ik3_$name.o build/diag/ik4_$name.o build/tick.hip.o build/hull.hip.o build/diag/kin_$name.o build/host_WalkingControllers.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/diag/libwcqp_$name.so build/common.cpp.o build/mpc.hip.o build/diag/ik_$name.o build/diag/ik2_$name.o build/diag/ik3_$name.o build/diag/ik4_$name.o build/diag/tick_$name.o build/hull.hip.o build/diag/kin_$name.o build/host_WalkingControllers.o
 echo built build/diag/libwcqp_$name.so

@@ -86,7 +86,12 @@ static_assert(PER_INST * 8 * 4 * 12 <= 160 * 1024, "12 blocks per CU");
 #define WCQP_IK4_KS 4                 // bounds kept replicated in registers (more: the slot-per-lane loop)
 #endif
 
-#ifdef WCQP_IK_STAMPS
+#if defined(WCQP_TICK_STAMPS)
+// diagnostic build (tools/build_variant.sh tstamps -DWCQP_TICK_STAMPS): s_memtime at the phase boundaries of the TICK kernel's body, per
+// workgroup, the last tick of a launch wins (TickDev::stamps; tools/stamps_tick.py)
+#define WCQP_STAMP(k) do { if constexpr (TICK) { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+                           if (lane == 0 && td.stamps) td.stamps[(size_t)blk * 16 + (k)] = t__; } } while (0)
+#elif defined(WCQP_IK_STAMPS)
 #define WCQP_STAMP(k) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
                            if (lane == __ffsll((long long)__ballot(true)) - 1) reinterpret_cast<unsigned long long*>(ferr_out)[(size_t)blockIdx.x * 16 + (k)] = t__; } while (0)
 #else
@@ -256,6 +261,13 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const int side = ((tick_now + mreg.phase0) % (2 * td.step_ticks)) / td.step_ticks;
             const int cs[2] = {j, var1 ? col1 : 0};
             double* TW = S + K_TW;
+            int kup[2][3], ksub[2];                 // the joints' pointer-jumping links and subtree ends: from the model table in LDS
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const int* ip = reinterpret_cast<const int*>(kmodel + cs[s_] * wcqp_tick::kKinTabJoint + wcqp_tick::kKinTabInts);
+                kup[s_][0] = ip[0]; kup[s_][1] = ip[1]; kup[s_][2] = ip[2]; ksub[s_] = ip[3];
+            }
+            const int kfj = reinterpret_cast<const int*>(kmodel + wcqp_tick::kKinTabRoot + 4)[j < 3 ? j : 0];
             {
             double Ra[2][9], pa[2][3];
 #pragma unroll
@@ -269,8 +281,10 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 joint_rotation(R0, axl, s_ == 0 ? q0 : q1, Ra[s_]);
             }
             // the tree in base coordinates by pointer jumping (kin.hip): after round r a frame is relative to its 2^(r+1)-th ancestor
-#pragma unroll 1
-            for (int r = 0; r < td.kin_rounds; ++r) {
+            const int n_rounds = td.kin_rounds;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (r >= n_rounds) break;
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
                     if (s_ == 0 || var1) {
@@ -283,7 +297,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 wcqp::wave_lds_fence();
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
-                    const int u = td.kin_up[r][cs[s_]];
+                    const int u = kup[s_][r];
                     if (u >= 0 && (s_ == 0 || var1)) {
                         const double* T = TW + u * 12;
                         double Rp[9], pp[3], Rn[9], pn[3];
@@ -315,7 +329,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const int fi = j < 3 ? j : 0;
             double Rf[9], pf[3];
             {
-                const double* T = TW + td.kin_frame_joint[fi] * 12;
+                const double* T = TW + kfj * 12;
                 const double* ft = kmodel + wcqp_tick::kKinTabFrames + fi * 12;
                 double Rj[9], pj[3], fR[9], fp[3];
 #pragma unroll
@@ -437,7 +451,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) {
                 const int c = cs[s_];
-                const double* Pe = PS + td.kin_sub_end[c] * 4;
+                const double* Pe = PS + ksub[s_] * 4;
                 const double* Pb = PS + (c > 0 ? c - 1 : 0) * 4;
                 const double z = c > 0 ? 1.0 : 0.0;
                 const double ms = Pe[3] - z * Pb[3];
@@ -466,6 +480,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
             for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
             sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
+            WCQP_STAMP(12);
             load_lane_constants();
             load_handoff();
             load_previous_set();
@@ -555,6 +570,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 g_twr = (code == 1 || code == 2) ? 0.0 : tw;
             }
             if (live && j == 0 && g_ok == 0.0) td.mpc_fail[inst] += 1;
+            WCQP_STAMP(13);
         }
         // the scalar settings are read only now: in front of the column loads their (cold) scalar-cache misses would sit in
         // the same s_waitcnt as the Jacobian pointers and hold the 36 loads back
@@ -1420,6 +1436,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             if (var1) wcqp_tick::tick_post_joint(td, i_, tick_now, col1, ik_ok, dq1);
             if (j == 0 && (!ik_ok || stopped)) td.ik_fail[i_] += 1;       // tick_post_instance without the contact pair: the MPC part derives its own
         }
+        WCQP_STAMP(14);
     }
     if (ferr_out) {
         // b - J nu for the 12 foot rows (osqp.cpp:430-454, qp.cpp:364-401) with nu = (v_base, dq) and

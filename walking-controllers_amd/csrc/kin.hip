@@ -471,7 +471,7 @@ int kin_enqueue_tick(wcqp_kin_t h, int batch, const wcqp_tick::KinTick& kt, cons
 }
 // The model as the tick kernel's fused kinematics phase reads it (tick_device.h: TickDev::kin_tab and the int tables): false when
 // the tree does not qualify (subtrees that are not index ranges, more than 3 pointer-jumping rounds, a joint on two frame paths)
-bool kin_fused_tables(wcqp_kin_t h, std::vector<double>& tab, int up[3][24], int sub_end[24], int frame_joint[3], int* n_rounds) {
+bool kin_fused_tables(wcqp_kin_t h, std::vector<double>& tab, int* n_rounds) {
     if (!h) return false;
     const KinDev& d = h->hd;
     unsigned m[3]; int stride = 0, off_d = 0;
@@ -483,17 +483,18 @@ bool kin_fused_tables(wcqp_kin_t h, std::vector<double>& tab, int up[3][24], int
         for (int k = 0; k < 9; ++k) r[k] = d.R0[j][k];
         for (int k = 0; k < 3; ++k) { r[9 + k] = d.p0[j][k]; r[12 + k] = d.axis[j][k]; r[15 + k] = d.com[j][k]; }
         r[18] = d.mass[j];
-        sub_end[j] = d.sub_end[j];
-        for (int q = 0; q < 3; ++q) up[q][j] = d.up[q][j];
+        const int ints[4] = {d.up[0][j], d.up[1][j], d.up[2][j], d.sub_end[j]};
+        std::memcpy(r + wcqp_tick::kKinTabInts, ints, sizeof(ints));
     }
     for (int f = 0; f < 3; ++f) {
         double* r = &tab[wcqp_tick::kKinTabFrames + (size_t)f * 12];
         for (int k = 0; k < 9; ++k) r[k] = d.frame_R[f][k];
         for (int k = 0; k < 3; ++k) r[9 + k] = d.frame_p[f][k];
-        frame_joint[f] = d.frame_joint[f];
     }
     for (int k = 0; k < 3; ++k) tab[wcqp_tick::kKinTabRoot + k] = d.root_com[k];
     tab[wcqp_tick::kKinTabRoot + 3] = d.root_mass;
+    const int fj[4] = {d.frame_joint[0], d.frame_joint[1], d.frame_joint[2], 0};
+    std::memcpy(&tab[wcqp_tick::kKinTabRoot + 4], fj, sizeof(fj));
     *n_rounds = d.n_rounds;
     return true;
 }

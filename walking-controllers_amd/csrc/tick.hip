@@ -194,7 +194,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     // kinematics fused into the solve kernel (default), or a kinematics launch per tick handing over compact records / dense Jacobians
     std::vector<double> ktab;
     const bool fusedk = masks_ok && params->kin_handoff == WCQP_KIN_HANDOFF_FUSED && N < kGainsLdsStages &&
-                        wcqp::kin_fused_tables(h->kin, ktab, d.kin_up, d.kin_sub_end, d.kin_frame_joint, &d.kin_rounds);
+                        wcqp::kin_fused_tables(h->kin, ktab, &d.kin_rounds);
     const bool compact = masks_ok && !fusedk && params->kin_handoff != WCQP_KIN_HANDOFF_DENSE;
     if (d.skew) {
         A_(d.mst, B * 16); A_(d.hand, 2 * B * kHandLen); A_(d.live_A, B * 16); A_(d.live_b, B * 8); A_(d.live_nc, B); A_(d.sel_built, B);
@@ -223,6 +223,9 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
         if (compact) { h->kt.jcomp = jcomp; h->kt.cstride = cstride; h->kt.coff_d = coff_d; }
     }
     d.ref_traj = ref; d.hull_tab_A = hA; d.hull_tab_b = hb; d.hull_tab_nc = hn; d.phase0 = ph; d.swing_twist = sw;
+#ifdef WCQP_TICK_STAMPS
+    if (d.skew && dev_alloc(h, &d.stamps, ((B + 3) / 4) * 16) != WCQP_OK) { wcqp_tick_destroy(h); return WCQP_E_NOMEM; }
+#endif
     if (d.skew) {
         if (dev_alloc(h, &h->d_dev, 1) != WCQP_OK) { wcqp_tick_destroy(h); return WCQP_E_NOMEM; }
         if (hipMemcpy(h->d_dev, &d, sizeof(TickDev), hipMemcpyHostToDevice) != hipSuccess) { wcqp_tick_destroy(h); return WCQP_E_HIP; }
@@ -380,6 +383,16 @@ int wcqp_tick_splice_reference(wcqp_tick_t h, int32_t from_tick, int32_t n_stage
                                   (size_t)n_stages * 16, (size_t)d.batch, hipMemcpyHostToDevice, (hipStream_t)stream));
     return WCQP_OK;
 }
+
+#ifdef WCQP_TICK_STAMPS
+// diagnostic builds only: the phase stamps of every workgroup's last tick ([workgroups][16])
+int wcqp_tick_debug_stamps(wcqp_tick_t h, unsigned long long* out, int32_t n) {
+    if (!h || !out || !h->d.stamps || n > ((h->d.batch + 3) / 4) * 16) return WCQP_E_INVALID;
+    WCQP_HIP_TRY(hipDeviceSynchronize());
+    WCQP_HIP_TRY(hipMemcpy(out, h->d.stamps, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return WCQP_OK;
+}
+#endif
 
 int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
     if (!h || !out) return WCQP_E_INVALID;

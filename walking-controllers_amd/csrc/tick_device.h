@@ -64,19 +64,20 @@ struct TickDev {
     // ---- kinematics FUSED into the tick kernel (ik4.hip, JSRC = 2): no kinematics launch, no Jacobian hand-off through memory
     // at all - the wave that solves a robot's IK first evaluates its forward kinematics and Jacobian columns, 16 lanes per
     // robot, two joints per lane - and the kernel can then walk through many ticks per launch, like the constant-Jacobian form.
-    // kin_tab: the model as one table of doubles (staged into LDS once per launch): [dof][20] = R0 9 | p0 3 | axis 3 | com 3 |
-    // mass | pad, then [3][12] attached frames R 9 | p 3, then root_com 3, root_mass.
+    // kin_tab: the model as one table of doubles (staged into LDS once per launch): [dof][22] = R0 9 | p0 3 | axis 3 | com 3 |
+    // mass | four ints: the joint's pointer-jumping links of rounds 0..2, the last joint of its subtree | pad; then [3][12]
+    // attached frames R 9 | p 3; then root_com 3, root_mass, three ints: the joints the frames are attached to.
     int kin_fused, kin_rounds;
     const double* kin_tab;
-    int kin_up[3][24], kin_sub_end[24], kin_frame_joint[3];
     // ---- logger rows (wcqp_tick_params.logger_ticks): the 53 values WalkingModule hands its logger per tick
     // (WM/src/WalkingModule.cpp:800-810, column names :1231-1250), kept for the first logger_ticks ticks
     double* log_rows;   // [logger_ticks][B][kLoggerCols]
     int logger_ticks;
+    unsigned long long* stamps;     // diagnostic builds (-DWCQP_TICK_STAMPS): [workgroups][16] s_memtime at the phase boundaries; else NULL
 };
 constexpr int kHandLen = 14;
 constexpr int kLoggerCols = 53;
-constexpr int kKinTabJoint = 20, kKinTabFrames = 20 * kDof, kKinTabRoot = kKinTabFrames + 36, kKinTabSize = kKinTabRoot + 4;
+constexpr int kKinTabJoint = 22, kKinTabInts = 19, kKinTabFrames = kKinTabJoint * kDof, kKinTabRoot = kKinTabFrames + 36, kKinTabSize = kKinTabRoot + 6;
 constexpr int kGainsLdsStages = 64;        // fused kinematics: the MPC's gain blocks Gr ((N + 1) x 2 x 2, N <= 63) sit in LDS beside the model
 
 // offset (doubles) of joint c's record inside a robot's compact Jacobian block, and the frame the joint belongs to

@@ -49,7 +49,7 @@ int kin_prepare(wcqp_kin_t h);
 int hull_tables_from_state(int batch, const double* foot_rect_host, const double* state_dev, int state_len,
                            double* tab_A, double* tab_b, int* tab_nc, hipStream_t stream);
 bool kin_compact_layout(wcqp_kin_t h, unsigned masks[3], int* stride, int* off_d);
-bool kin_fused_tables(wcqp_kin_t h, std::vector<double>& tab, int up[3][24], int sub_end[24], int frame_joint[3], int* n_rounds);   // kin.hip: the model for the tick kernel's own kinematics phase   // kin.hip: layout of the tick's compact Jacobian hand-off
+bool kin_fused_tables(wcqp_kin_t h, std::vector<double>& tab, int* n_rounds);   // kin.hip: the model for the tick kernel's own kinematics phase   // kin.hip: layout of the tick's compact Jacobian hand-off
 
 // ---- wave-level helpers used by the kernels (gfx950, wave64) -------------------------
 #if defined(__HIPCC__)
