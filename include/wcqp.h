@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define WCQP_VERSION 301
+#define WCQP_VERSION 302
 
 /* return codes */
 #define WCQP_OK              0
@@ -456,6 +456,8 @@ typedef struct wcqp_tick_outputs {  /* HOST pointers, any may be NULL */
     int64_t* hot_try; int64_t* hot_hit;    /* [B] ticks on which the previous active set was tried / accepted (IK hot start) */
     int32_t* tick;              /* ticks executed so far                                       */
     double* logger;             /* [logger_ticks][B][53] logger rows (wcqp_tick_params.logger_ticks)   */
+    uint32_t* active_lower; uint32_t* active_upper;   /* [B] the IK's active joint-velocity bounds of the LAST tick (bit i = joint i):
+                                                         what the next tick's hot start begins from                               */
 } wcqp_tick_outputs;
 
 typedef struct wcqp_tick_s* wcqp_tick_t;

@@ -123,7 +123,7 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
     state_now = data["state0"].copy()
     hull_cur = [None] * B; hull_code = -np.ones(B, np.int64)
     J_now = [None] * B
-    active_log = []
+    act_lo = np.zeros((n_ticks, B), np.uint32); act_up = np.zeros((n_ticks, B), np.uint32)     # every tick's active bounds, bit i = joint i
     logger = np.zeros((logger_ticks, B, 53))
 
     def rpy(R9):
@@ -213,6 +213,7 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
             try:
                 res_ik = qs.ik_exact(ik_params, qs.ik_inputs_from_batch(one, 0), ik_form)
                 dq[i] = res_ik["dq"]
+                act_lo[t, i] = sum(1 << int(j) for j in res_ik["lower"]); act_up[t, i] = sum(1 << int(j) for j in res_ik["upper"])
                 if t < logger_ticks:
                     logger[t, i, 41:47] = res_ik["foot_err_left"]; logger[t, i, 47:53] = res_ik["foot_err_right"]
             except qs.QPOracleError:
@@ -224,4 +225,5 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
         dcm = c.a * dcm + c.b * u0 + p.noise * w
         zmp_meas = u0.copy(); u_prev = u0.copy()
         u0_log[t] = u0; dq_log[t] = dq
-    return dict(u0_log=u0_log, dq_log=dq_log, q_des=q_des, dcm=dcm, com=com, mpc_fail=mpc_fail, ik_fail=ik_fail, logger=logger)
+    return dict(u0_log=u0_log, dq_log=dq_log, q_des=q_des, dcm=dcm, com=com, mpc_fail=mpc_fail, ik_fail=ik_fail, logger=logger,
+                active_lower=act_lo[-1], active_upper=act_up[-1], active_lower_log=act_lo, active_upper_log=act_up)

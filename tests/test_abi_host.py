@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(wca):
     lib = wca.capi.lib()
     for s in declared:
         assert getattr(lib, s) is not None
-    assert lib.wcqp_version() == 301
+    assert lib.wcqp_version() == 302
     assert lib.wcqp_strerror(-4).decode().startswith("HIP")
 
 

@@ -53,10 +53,20 @@ def test_tick_pipeline_matches_cpu_restatement(wca, qs, ik_algorithm):
         assert np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8
         assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9
         assert np.abs(out["dcm"] - ref["dcm"]).max() <= 1e-9 and np.abs(out["com"] - ref["com"]).max() <= 1e-9
+        # the active joint-velocity bounds the last tick ended on (what the next tick's hot start begins from): bit-exact
+        assert np.array_equal(out["active_lower"], ref["active_lower"]) and np.array_equal(out["active_upper"], ref["active_upper"])
         if not use_graph:
             eager = out
     assert np.array_equal(out["u0_log"], eager["u0_log"]) and np.array_equal(out["dq_log"], eager["dq_log"])   # graph == eager, bitwise
     assert np.abs(ref["dq_log"]).max() == pytest.approx(vmax, abs=1e-12)        # velocity limits really bind
+    # ... and stopped at a tick where they do, the pipeline hands back exactly the oracle's active sets
+    tb = int(np.nonzero((ref["active_lower_log"] | ref["active_upper_log"]).any(axis=1))[0][-1]) + 1
+    pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm))
+    pipe.upload(d)
+    pipe.run(tb)
+    part = pipe.download()
+    assert np.array_equal(part["active_lower"], ref["active_lower_log"][tb - 1]) and np.array_equal(part["active_upper"], ref["active_upper_log"][tb - 1])
+    assert (part["active_lower"] | part["active_upper"]).any()
     # several ticks per launch (0: all of a run() call; 7: launches of 7, 7, ... and a remainder), split over two run() calls
     for k in (0, 7):
         pipe = wca.TickPipeline(B, T, wca.MpcSolver(), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, algorithm=ik_algorithm), log_ticks=T,
@@ -65,7 +75,7 @@ def test_tick_pipeline_matches_cpu_restatement(wca, qs, ik_algorithm):
         pipe.run(61); pipe.run(T - 61)
         multi = pipe.download()
         assert multi["tick"] == T
-        for key in ("u0_log", "dq_log", "q_des", "dcm", "com", "ik_fail", "mpc_fail", "hot_try", "hot_hit"):
+        for key in ("u0_log", "dq_log", "q_des", "dcm", "com", "ik_fail", "mpc_fail", "hot_try", "hot_hit", "active_lower", "active_upper"):
             assert np.array_equal(multi[key], eager[key]), (k, key)
 
 
@@ -263,6 +273,7 @@ def _kin_tick_against_oracle(wca, qs, B, T, vmax, ik_algorithm, handoff=0, graph
         assert np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8
         assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9
         assert np.abs(out["dcm"] - ref["dcm"]).max() <= 1e-9 and np.abs(out["com"] - ref["com"]).max() <= 1e-9
+        assert np.array_equal(out["active_lower"], ref["active_lower"]) and np.array_equal(out["active_upper"], ref["active_upper"])
         outs.append(out)
     return d, ref, outs, vmax
 

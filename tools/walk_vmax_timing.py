@@ -18,6 +18,7 @@ for up in (0.3, 0.4, 0.6, 1.5):
     p.upload(d); p.run(24); wca.capi.stream_synchronize()
     t0 = time.perf_counter(); p.run(1000); wca.capi.stream_synchronize(); dt = time.perf_counter() - t0
     o = p.download()
-    print(json.dumps({"upper_body_vmax": up, "us_per_tick": 1e6 * dt / 1000, "qp_per_s": 2 * B * 1000 / dt, "robots_failed": int((o["ik_fail"] > 0).sum()),
+    nact = np.array([bin(int(a) | int(b)).count("1") for a, b in zip(o["active_lower"], o["active_upper"])])
+    print(json.dumps({"upper_body_vmax": up, "active_bounds_per_robot_hist_at_last_tick": np.bincount(nact, minlength=9)[:12].tolist(), "us_per_tick": 1e6 * dt / 1000, "qp_per_s": 2 * B * 1000 / dt, "robots_failed": int((o["ik_fail"] > 0).sum()),
                       "hot_start_tried_frac": float(o["hot_try"].sum()) / (B * T), "hot_start_hit_rate": float(o["hot_hit"].sum()) / max(1, int(o["hot_try"].sum()))}), flush=True)
     p.close()

@@ -132,7 +132,7 @@ class TickInputs(C.Structure):
 
 
 class TickOutputs(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("u0_log", "dq_log", "q_des", "dcm", "com", "mpc_fail", "ik_fail", "hot_try", "hot_hit", "tick", "logger")]
+    _fields_ = [(k, C.c_void_p) for k in ("u0_log", "dq_log", "q_des", "dcm", "com", "mpc_fail", "ik_fail", "hot_try", "hot_hit", "tick", "logger", "active_lower", "active_upper")]
 
 
 _lib: Optional[C.CDLL] = None
@@ -445,7 +445,8 @@ class TickPipeline:
         B, L, D = self.batch, self.log_ticks, self.dof
         o = dict(u0_log=np.zeros((L, B, 2)), dq_log=np.zeros((L, B, D)), q_des=np.zeros((B, D)), dcm=np.zeros((B, 2)),
                  com=np.zeros((B, 2)), mpc_fail=np.zeros(B, np.int64), ik_fail=np.zeros(B, np.int64),
-                 hot_try=np.zeros(B, np.int64), hot_hit=np.zeros(B, np.int64), tick=np.zeros(1, np.int32))
+                 hot_try=np.zeros(B, np.int64), hot_hit=np.zeros(B, np.int64), tick=np.zeros(1, np.int32),
+                 active_lower=np.zeros(B, np.uint32), active_upper=np.zeros(B, np.uint32))
         if self.logger_ticks > 0:
             o["logger"] = np.zeros((self.logger_ticks, B, 53))
         outs = TickOutputs(**{k: (o[k].ctypes.data if k in o else None) for k, _ in TickOutputs._fields_})

@@ -139,7 +139,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev& td, double (*smem)[PER_INST], int blk,
                 const int tick_now = 0, const bool do_mpc = true, const double* kmodel = nullptr, const double* gr_lds = nullptr,
-                const MpcPairArgs* pm = nullptr)
+                const MpcPairArgs* pm = nullptr, double* carry = nullptr)
 {
     static_assert(!(TICK && PAIR), "the tick kernel carries its own MPC chain");
     constexpr bool COMPACT = JSRC == 1;
@@ -216,8 +216,14 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
             sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
         }
-        q0 = qpos[inst * kDof + j];
-        q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
+        if constexpr (TICK) {
+            // the tick kernel walks through the ticks: this lane's joint positions (and previous velocities) are carried from the
+            // post step of one tick to the next in registers - what the post step stores is never re-read inside a launch
+            q0 = carry[0]; q1 = carry[1];
+        } else {
+            q0 = qpos[inst * kDof + j];
+            q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
+        }
         double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0, g_ok = 1.0, g_sw = 0.0, g_h0 = 0.0;
         auto load_handoff = [&]() {
             // hand-off of MPC(t): desired CoM position / velocity (WalkingModule.cpp:686-695), the plant's CoM, did the MPC end usable
@@ -484,8 +490,6 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             load_lane_constants();
             load_handoff();
             load_previous_set();
-            q0 = qpos[inst * kDof + j];          // (again: not held across the phase)
-            q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
             wcqp::wave_lds_fence();              // everything of the kinematics scratch has been read
             if (j >= 11 && j < 14) {
                 // B_R - B_L, B_C - B_L for the row operations, column cm: B_f = -S(p_f - p_base), column cm = e_cm x (p_f - p_base) -
@@ -1432,8 +1436,19 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         const bool ik_ok = st_code == WCQP_STATUS_SOLVED;
         if (live) {
             const int i_ = (int)inst;
-            wcqp_tick::tick_post_joint(td, i_, tick_now, j, ik_ok, dq0);
-            if (var1) wcqp_tick::tick_post_joint(td, i_, tick_now, col1, ik_ok, dq1);
+            // q <- Integrator(dq) (WalkingModule.cpp:741-744; tick_post_joint with the carried values): stored for the next launch
+            // / the download, carried for the next tick
+            const double v0 = (ik_ok && !stopped) ? dq0 : 0.0, v1 = (ik_ok && !stopped) ? dq1 : 0.0;
+            carry[0] += 0.5 * td.dT * (v0 + carry[2]); carry[2] = v0;
+            const size_t g0 = (size_t)i_ * kDof + j;
+            td.q_des[g0] = carry[0]; td.dq_prev[g0] = v0;
+            if (tick_now < td.log_ticks) td.dq_log[(size_t)tick_now * td.batch * kDof + g0] = v0;
+            if (var1) {
+                carry[1] += 0.5 * td.dT * (v1 + carry[3]); carry[3] = v1;
+                const size_t g1 = (size_t)i_ * kDof + col1;
+                td.q_des[g1] = carry[1]; td.dq_prev[g1] = v1;
+                if (tick_now < td.log_ticks) td.dq_log[(size_t)tick_now * td.batch * kDof + g1] = v1;
+            }
             if (j == 0 && (!ik_ok || stopped)) td.ik_fail[i_] += 1;       // tick_post_instance without the contact pair: the MPC part derives its own
         }
         WCQP_STAMP(14);
@@ -1523,11 +1538,20 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             wcqp::wave_lds_fence();
         }
         const int t0 = td.tick2[phase];
+        double carry[4];                     // this lane's two joints: q_des, q_des, dq_prev, dq_prev
+        {
+            const int lane_ = threadIdx.x, j_ = lane_ & 15;
+            const long ir = (long)blockIdx.x * 4 + (lane_ >> 4);
+            const long i_ = ir < batch ? ir : (long)batch - 1;
+            const bool v1_ = j_ < kDof - 16;
+            carry[0] = td.q_des[i_ * kDof + j_]; carry[1] = td.q_des[i_ * kDof + (v1_ ? j_ + 16 : 0)];
+            carry[2] = td.dq_prev[i_ * kDof + j_]; carry[3] = td.dq_prev[i_ * kDof + (v1_ ? j_ + 16 : 0)];
+        }
 #pragma unroll 1
         for (int k = 0; k < n_inner; ++k) {
             __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop (its registers are all spoken for)
             ik4_body<TICK, JSRC, false, LOG>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
-                                             (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains);
+                                             (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains, nullptr, carry);
             // tick t + 1 of this wave reads what tick t wrote (other lanes of the same wave): visible before it starts
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();

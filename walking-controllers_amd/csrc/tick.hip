@@ -402,6 +402,7 @@ int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out) {
 #define DN_(dst, src, n) if (dst) WCQP_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
     DN_(out->u0_log, d.u0_log, (size_t)d.log_ticks * B * 16); DN_(out->dq_log, d.dq_log, (size_t)d.log_ticks * B * kDof * 8);
     DN_(out->q_des, d.q_des, B * kDof * 8);
+    DN_(out->active_lower, h->ik_lo, B * 4); DN_(out->active_upper, h->ik_up, B * 4);
     if (out->logger) {
         if (!d.log_rows) return WCQP_E_UNSUPPORTED;          // logger_ticks = 0, or an IK algorithm without the fused tick kernel
         WCQP_HIP_TRY(hipMemcpy(out->logger, d.log_rows, (size_t)d.logger_ticks * B * kLoggerCols * 8, hipMemcpyDeviceToHost));
