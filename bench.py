@@ -95,6 +95,10 @@ def main():
                          "owns four robots and walks through the steps on its own, the MPC of a step in the shadow of its IK's Jacobian loads; "
                          "W wavefronts share a robot group (way w takes steps w, w + W, ...; each way has its own output buffers, like a "
                          "pipeline).  0 = one launch per step on --pipelines streams (round-2 form)")
+    ap.add_argument("--plan-queue", type=int, choices=[0, 1], default=0,
+                    help="plan mode: 1 = the one launch hands out (step, robot group) units from a work queue instead of fixed ways - as many "
+                         "wavefronts as are resident at once, each taking the next unit when it is done with one; every timed step then has "
+                         "output buffers of its own (any two steps may be in flight together) and EVERY timed step is checked against the goldens")
     ap.add_argument("--step-graph", action="store_true", help="qp workload: replay ONE hipGraph that holds the timed steps as P parallel chains (one per "
                     "pipeline) instead of enqueueing them launch by launch.  Measured and left off: 8.9-9.2 us per step against 8.5-9.1 in "
                     "the driver's 20-step form, 8.9 against 7.0 at 200 steps (profiles/r03_step_graph_ab.txt)")
@@ -168,8 +172,10 @@ def main():
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
     use_plan = (args.plan_ways > 0 and not (args.exchange and dist is not None) and args.streams in (0, 1) and args.ik_jac == "mixed"
                 and not args.step_graph)
+    plan_ways = 0 if args.plan_queue else args.plan_ways                        # wcqp_qp_plan_create: 0 = work queue
     if use_plan:
-        P = args.pipelines if args.pipelines > 0 else args.plan_ways           # one output buffer set per way
+        # one output buffer set per way; with the work queue one per timed step
+        P = args.pipelines if args.pipelines > 0 else (args.steps if args.plan_queue else args.plan_ways)
     else:
         P = args.pipelines if args.pipelines > 0 else (1 if (args.exchange and dist is not None) else 3)
 
@@ -315,7 +321,7 @@ def main():
     # its stream, the chains forked from and joined into the capture stream), captured from the very wcqp_qp_enqueue_steps
     # call the launch-by-launch form makes; set-up: capture, instantiate, one replay (the first launch of a graph uploads
     # it).  A/B'd in round 3 and left OFF: the graph's dependent kernel nodes are dispatched no faster than the streams do it.
-    plan = wca.capi.QpPlan(mpc, ik, B, recs, ways=P) if (use_plan and recs is not None) else None
+    plan = wca.capi.QpPlan(mpc, ik, B, recs, ways=plan_ways) if (use_plan and recs is not None) else None
     step_graph = None
     if recs is not None and args.step_graph:
         try:
@@ -432,7 +438,7 @@ def main():
                 r.u0, r.mpc_status, r.mpc_active, r.mpc_margin = o["u0"], o["mstat"], o["mact"], o["mmar"]
                 r.J_left, r.J_right, r.J_neck, r.J_com, r.q, r.state = q_
                 r.dq, r.ik_status, r.active_lower, r.active_upper, r.foot_err, r.iters = o["dq"], o["istat"], o["ilo"], o["iup"], None, o["iit"]
-            pl = wca.capi.QpPlan(mpc, ik, B, r2, ways=P)
+            pl = wca.capi.QpPlan(mpc, ik, B, r2, ways=plan_ways)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = max(2, min(10, 2000 // max(1, n)))          # several launches in one bracket: the host work since the timed region let the clocks drop
             pl.enqueue(sp); pl.enqueue(sp)
@@ -479,13 +485,14 @@ def main():
             "batch_per_gpu": B, "global_batch": B * world, "horizon": NH, "dof": 23,
             "input_sets": K, "input_bytes_per_set": set_bytes, "ik_jacobian_structure": args.ik_jac, "pipelines": P,
             "host_enqueue_us_per_step": 1e6 * t_enq / args.steps,
-            "timed_steps_enqueued_as": ("ONE launch (wcqp_qp_plan_enqueue): qp_plan_kernel walks through the %d steps, %d wavefronts per robot group" % (args.steps, P)) if plan is not None
+            "timed_steps_enqueued_as": (("ONE launch (wcqp_qp_plan_enqueue): qp_plan_kernel, as many wavefronts as are resident at once take (step, robot group) units of the %d steps from a work queue" % args.steps) if args.plan_queue else
+                                        ("ONE launch (wcqp_qp_plan_enqueue): qp_plan_kernel walks through the %d steps, %d wavefronts per robot group" % (args.steps, P))) if plan is not None
                                        else (("one hipGraph launch: %d parallel chains of one-launch steps" % P) if step_graph is not None else "one wcqp_qp_enqueue_steps call, launch by launch"),
             "timed_region": "barrier + torch.cuda.synchronize() -> K steps -> completion events of every stream used (hipEventSynchronize), "
                             "MAX over ranks; the device-wide synchronize that follows adds %.0f us of host time with the device idle "
                             "(ms_per_step_incl_device_sync)" % (1e6 * (elapsed_sync - elapsed)),
             "ms_per_step_incl_device_sync": 1e3 * elapsed_sync / args.steps, "value_incl_device_sync": total_qp / elapsed_sync,
-            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ("; MPC and IK of a step in one launch" if not exch else "")) + (("; %d wavefronts per robot group (step i -> way i %% %d)" % (P, P) if plan is not None else "; %d independent batches in flight (step i -> pipeline i %% %d)" % (P, P)) if P > 1 else ""),
+            "parallelism": "batch sharded over %d GPU(s), no data-path collective%s%s" % (world, " + RCCL scatter/gather" if exch else "", "; MPC and IK batches on two HIP streams" if two_streams else ("; MPC and IK of a step in one launch" if not exch else "")) + ((("; work queue over (step, robot group) units" if args.plan_queue else "; %d wavefronts per robot group (step i -> way i %% %d)" % (P, P)) if plan is not None else "; %d independent batches in flight (step i -> pipeline i %% %d)" % (P, P)) if P > 1 else ""),
         },
         # the dominant kernel of the timed region: the one-launch step (IK + MPC workgroups; algorithmic bytes = both QPs'
         # per robot-tick) - or the IK kernel where the two calls are separate launches

@@ -293,7 +293,12 @@ int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch,
  * robots and walks through the records on its own - no launch, ramp-up or tail per step, the MPC of a record solved on the
  * IK's lanes while its Jacobians are in flight - and `ways` wavefronts share a robot group, way w taking records w, w + ways,
  * ... (two ways fill both wave slots of every SIMD at the BASELINE batch of 4096).  Records of DIFFERENT ways run
- * concurrently: they must not share output arrays (give each way its own, like the pipelines of separate streams).  Every
+ * concurrently: they must not share output arrays (give each way its own, like the pipelines of separate streams).
+ * ways = 0 is the WORK-QUEUE form: the launch has as many wavefronts as are resident at once (2 per SIMD), and each takes the
+ * next (record, robot group) unit - record-major - from a device-side queue when it is done with one, so that no wave slot
+ * idles while another wavefront still has records left (the tail of the fixed ways).  Any two records may then be in flight
+ * together and in any order: NO two records of the plan may share an output array.  The queue is re-armed by the launch itself;
+ * launches of ONE plan must be ordered (one stream at a time), different plans are independent.  Every
  * record needs both parts; the stream fields of the records are ignored (wcqp_qp_plan_enqueue names the stream).
  * WCQP_E_UNSUPPORTED unless the IK handle runs its default kernel with jacobian_structure = WCQP_IK_JAC_MIXED: use
  * wcqp_qp_enqueue_steps then.  Same results as the single calls, bit for bit.  The arrays the

@@ -1,6 +1,6 @@
 """Run by tests/test_gpu_parity.py::test_qp_plan_equals_the_single_calls in a process of its own (torch first, then libwcqp):
 a plan of 7 records (wcqp_qp_plan_*: ONE launch walks through them, `ways` wavefronts per robot group, each way with its own
-output buffers) against the single wcqp_mpc_solve_device / wcqp_ik_solve_device calls of the same records, bit for bit."""
+output buffers; ways = 0: (record, robot group) units handed out from a work queue) against the single wcqp_mpc_solve_device / wcqp_ik_solve_device calls of the same records, bit for bit."""
 import os, sys
 import numpy as np
 import torch
@@ -63,8 +63,11 @@ def main(B, ways, R=7, horizon=50):
 
 
 if __name__ == "__main__":
-    for B, ways in ((1, 1), (5, 3), (777, 2), (4096, 2), (4096, 9)):      # ragged batches; more ways than records
+    for B, ways in ((1, 1), (5, 3), (777, 2), (4096, 2), (4096, 9), (1, 0), (777, 0), (4096, 0)):      # ragged batches; more ways than records; 0 = work queue
+        # (4096 robots x 7 records = 7168 units for the 2048 wavefronts that are resident at once; the replay starts from the queue the first launch put back)
         main(B, ways)
+    main(8192, 0, R=5)
+    main(333, 0, R=3, horizon=200)
     main(333, 2, R=3, horizon=200)                                         # the shipped horizon: more than one 64-stage pass of the window
     main(64, 1, R=2, horizon=7)
     print("plan ok")

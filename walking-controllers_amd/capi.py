@@ -86,7 +86,8 @@ def qp_enqueue_steps(mpc, ik, batch, steps):
 
 class QpPlan:
     """wcqp_qp_plan_*: the records of qp_enqueue_steps uploaded once, replayed as ONE launch that walks through them; `ways`
-    wavefronts share a robot group (way w takes records w, w + ways, ...: records of different ways need their own outputs)."""
+    wavefronts share a robot group (way w takes records w, w + ways, ...: records of different ways need their own outputs);
+    ways = 0: a work queue over (record, robot group) units - every record needs outputs of its own."""
 
     def __init__(self, mpc, ik, batch, steps, ways=1):
         self._h = C.c_void_p()

@@ -609,13 +609,15 @@ struct wcqp_qp_plan_s {
     wcqp_ik_t ik = nullptr;
     int batch = 0, n_steps = 0, ways = 1;
     wcqp_qp_step* d_recs = nullptr;
+    unsigned* d_queue = nullptr;      // ways = 0: ticket counters + waves done (ik_common.h: kPlanQueues; qp_plan_kernel zeroes them itself)
+    int queue_grid = 0;
 };
 
 extern "C" {
 
 int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_steps, const wcqp_qp_step* steps, int32_t ways,
                         wcqp_qp_plan_t* out) {
-    if (!mpc || !ik || !out || batch < 1 || n_steps < 1 || !steps || ways < 1) return WCQP_E_INVALID;
+    if (!mpc || !ik || !out || batch < 1 || n_steps < 1 || !steps || ways < 0) return WCQP_E_INVALID;
     // one launch walks through the records: that is the base-eliminated kernel on Jacobians the caller declares MIXED (no
     // fall-back launch behind it), with the MPC on the IK's lanes
     const bool want4 = ik->p.algorithm == WCQP_IK_ALG_BASE_ELIM || ik->p.algorithm == WCQP_IK_ALG_DEFAULT;
@@ -635,6 +637,14 @@ int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_s
     if (hipMemcpy(p->d_recs, steps, (size_t)n_steps * sizeof(wcqp_qp_step), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(p->d_recs); delete p; return WCQP_E_HIP;
     }
+    if (ways == 0) {
+        p->queue_grid = wcqp_ik::ik4_plan_queue_grid(batch, n_steps);
+        if (p->queue_grid < 1 || hipMalloc(reinterpret_cast<void**>(&p->d_queue), wcqp_ik::kPlanQueueBytes) != hipSuccess ||
+            hipMemset(p->d_queue, 0, wcqp_ik::kPlanQueueBytes) != hipSuccess) {
+            if (p->d_queue) (void)hipFree(p->d_queue);
+            (void)hipFree(p->d_recs); delete p; return WCQP_E_HIP;
+        }
+    }
     *out = p;
     return WCQP_OK;
 }
@@ -643,12 +653,13 @@ int wcqp_qp_plan_enqueue(wcqp_qp_plan_t p, void* stream) {
     if (!p) return WCQP_E_INVALID;
     wcqp_mpc::MpcDeviceConsts c;
     wcqp::mpc_device_consts(p->mpc, &c);
-    return wcqp_ik::ik4_launch_plan(p->ik->d_prm, p->batch, p->d_recs, p->n_steps, p->ways, c, (hipStream_t)stream);
+    return wcqp_ik::ik4_launch_plan(p->ik->d_prm, p->batch, p->d_recs, p->n_steps, p->ways, c, (hipStream_t)stream, p->d_queue, p->queue_grid);
 }
 
 int wcqp_qp_plan_destroy(wcqp_qp_plan_t p) {
     if (!p) return WCQP_E_INVALID;
     if (p->d_recs) (void)hipFree(p->d_recs);
+    if (p->d_queue) (void)hipFree(p->d_queue);
     delete p;
     return WCQP_OK;
 }

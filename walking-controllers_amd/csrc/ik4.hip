@@ -121,6 +121,10 @@ struct MpcPairArgs {
     const double* x0; const double* ref; int ref_len; const double* u_prev;
     const double* hull_A; const double* hull_b; const int* hull_nc;
     double* u0; int* status; unsigned* active; double* margin;
+    // qp_plan_kernel's work queues: lane 0 draws the wave's next ticket from this counter (nullptr: none) BEHIND the record's loads -
+    // vmcnt retires in order, and a device-scope atomic issued in front of them would hold every load of the record back by its
+    // own, longer, round trip - and leaves it here for the bottom of the loop
+    unsigned* ticket_from = nullptr; unsigned ticket = 0;
 };
 
 // PAIR (a plan of steps, wcqp_qp_plan_*): the wave also solves the DCM-MPC QP of its four robots, its loads issued in front
@@ -139,7 +143,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev& td, double (*smem)[PER_INST], int blk,
                 const int tick_now = 0, const bool do_mpc = true, const double* kmodel = nullptr, const double* gr_lds = nullptr,
-                const MpcPairArgs* pm = nullptr, double* carry = nullptr)
+                MpcPairArgs* pm = nullptr, double* carry = nullptr)
 {
     static_assert(!(TICK && PAIR), "the tick kernel carries its own MPC chain");
     constexpr bool COMPACT = JSRC == 1;
@@ -543,6 +547,10 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         for (int r = 0; r < 3; ++r) { a0[15 + r] = jn[r * kNV + fc0]; a1[15 + r] = jn[r * kNV + fc1]; }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PAIR) {
+            if (pm->ticket_from && threadIdx.x == 0) pm->ticket = __hip_atomic_fetch_add(pm->ticket_from, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (PAIR) {
             // the DCM-MPC QP of the same four robots while the Jacobians are on their way: the operations of mpc_row_solve, in its order
             double ux, uy, u0x, u0y, margin;
@@ -1628,18 +1636,66 @@ void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 // `ways` workgroups per robot group the BASELINE batch (1024 robot groups) fills both wave slots of every SIMD.
 __global__ __launch_bounds__(64, WCQP_IK4_WAVES)
 void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups,
-                    wcqp_mpc::MpcDeviceConsts c)
+                    wcqp_mpc::MpcDeviceConsts c, unsigned* queue)
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
-    const int way = (int)blockIdx.x / groups, blk = (int)blockIdx.x % groups;
+    // ways > 0: workgroup (way, robot group) walks through records way, way + ways, ... of its group.
+    // ways = 0, work queues: unit u = (record u / groups, robot group u % groups), record-major.  kPlanQueues ticket counters,
+    // kPlanQueueStride bytes apart (one counter serves ~8e7 tickets/s - measured: every wave behind ONE counter ran at half the
+    // rate of the fixed ways, at every batch size - and the launch needs 1.5e8); ticket k of queue q is unit k kPlanQueues + q.
+    // A wave draws from its home queue, asking for the next ticket behind the record's loads (ik4_body; the answer is needed at the
+    // bottom: the atomic's round trip rides under the record's arithmetic), and goes round the other queues once its own has run out; it leaves
+    // when all of them have.  queue[kPlanQueues * stride] counts the waves that are done: the last one zeroes everything.
+    const bool dynamic = ways == 0;
+    unsigned z = threadIdx.x;
+    __asm__ volatile("" : "+v"(z));
+    z >>= 6;          // an opaque per-lane zero in the ticket address: with a wave-uniform address hipcc's atomic optimizer rewrites the add into
+                      // "count the lanes, one atomic, s_waitcnt vmcnt(0), redistribute" - a synchronous round trip at the top of every record
+    constexpr unsigned QS = wcqp_ik::kPlanQueueStride / 4u;
+    const unsigned total = (unsigned)n_steps * (unsigned)groups;
+    unsigned home = blockIdx.x % wcqp_ik::kPlanQueues;
+    // the next unit of any queue, starting at `home` (synchronous): total when every queue has run out
+    auto draw = [&]() -> unsigned {
+        for (unsigned tried = 0; tried < wcqp_ik::kPlanQueues; ++tried) {
+            unsigned k = 0;
+            if (threadIdx.x == 0) k = __hip_atomic_fetch_add(queue + home * QS + z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)k) * wcqp_ik::kPlanQueues + home;
+            if (u < total) return u;
+            home = (home + 1u) % wcqp_ik::kPlanQueues;
+        }
+        return total;
+    };
+    int r = (int)blockIdx.x / groups, blk = (int)blockIdx.x % groups;
+    if (dynamic) {
+        const unsigned u = draw();
+        r = (int)(u / (unsigned)groups); blk = (int)(u % (unsigned)groups);
+    }
 #pragma unroll 1
-    for (int r = way; r < n_steps; r += ways) {
+    while (r < n_steps) {
         __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop
+        // (the record's pointers come out of memory: as_global says what a kernel argument would have said - gptr.h)
+        using wcqp::as_global;
         const wcqp_qp_step& s = recs[r];
-        MpcPairArgs m{c, s.x0, s.ref, s.ref_len, s.u_prev, s.hull_A, s.hull_b, s.hull_nc, s.u0, s.mpc_status, s.mpc_active, s.mpc_margin};
-        ik4_body<false, 0, true>(prm, batch, s.J_left, s.J_right, s.J_neck, s.J_com, s.q, s.state, s.dq, s.ik_status, s.active_lower, s.active_upper,
-                                 s.foot_err, s.iters, wcqp_tick::TickDev{}, smem, blk, 0, true, nullptr, nullptr, &m);
+        MpcPairArgs m{c, as_global(s.x0), as_global(s.ref), s.ref_len, as_global(s.u_prev), as_global(s.hull_A), as_global(s.hull_b), as_global(s.hull_nc),
+                      as_global(s.u0), as_global(s.mpc_status), as_global(s.mpc_active), as_global(s.mpc_margin),
+                      dynamic ? queue + home * QS + z : nullptr, 0u};
+        ik4_body<false, 0, true>(prm, batch, as_global(s.J_left), as_global(s.J_right), as_global(s.J_neck), as_global(s.J_com), as_global(s.q), as_global(s.state),
+                                 as_global(s.dq), as_global(s.ik_status), as_global(s.active_lower), as_global(s.active_upper),
+                                 as_global(s.foot_err), as_global(s.iters), wcqp_tick::TickDev{}, smem, blk, 0, true, nullptr, nullptr, &m);
         wcqp::wave_lds_fence();
+        if (dynamic) {
+            unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)m.ticket) * wcqp_ik::kPlanQueues + home;
+            if (u >= total) { home = (home + 1u) % wcqp_ik::kPlanQueues; u = draw(); }
+            r = (int)(u / (unsigned)groups); blk = (int)(u % (unsigned)groups);
+        } else {
+            r += ways;
+        }
+    }
+    if (dynamic && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(queue + wcqp_ik::kPlanQueues * QS, 1u) == gridDim.x - 1) {
+            for (unsigned q = 0; q <= wcqp_ik::kPlanQueues; ++q) queue[q * QS] = 0u;
+        }
     }
 }
 
@@ -1647,11 +1703,20 @@ void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcq
 
 namespace wcqp_ik {
 
+int ik4_plan_queue_grid(int batch, int n_steps) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return -1;
+    const long long total = (long long)((batch + 3) / 4) * n_steps, slots = (long long)cus * 4 * WCQP_IK4_WAVES;   // waves that are resident at once
+    return (int)(total < slots ? total : slots);
+}
+
 int ik4_launch_plan(const IkDeviceParams* d_prm, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways,
-                    const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream) {
-    if (!d_prm || !d_recs || batch < 1 || n_steps < 1 || ways < 1) return WCQP_E_INVALID;
+                    const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream, unsigned* d_queue, int queue_grid) {
+    if (!d_prm || !d_recs || batch < 1 || n_steps < 1 || ways < 0 || (ways == 0 && (!d_queue || queue_grid < 1))) return WCQP_E_INVALID;
     const int groups = (batch + 3) / 4;
-    hipLaunchKernelGGL(qp_plan_kernel, dim3((unsigned)(groups * ways)), dim3(64), 0, stream, d_prm, batch, d_recs, n_steps, ways, groups, c);
+    if ((long long)groups * n_steps >= (1ll << 31)) return WCQP_E_INVALID;
+    const unsigned grid = ways == 0 ? (unsigned)queue_grid : (unsigned)(groups * ways);
+    hipLaunchKernelGGL(qp_plan_kernel, dim3(grid), dim3(64), 0, stream, d_prm, batch, d_recs, n_steps, ways, groups, c, d_queue);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }

@@ -8,6 +8,7 @@
 #pragma once
 #include <limits>
 #include "wcqp_internal.h"
+#include "gptr.h"
 
 namespace wcqp_mpc {
 
@@ -15,7 +16,7 @@ constexpr int kLanesPerInstance = 16;   // one DPP row per instance, 4 instances
 constexpr int kInstPerWave = 64 / kLanesPerInstance;
 
 struct MpcDeviceConsts {
-    const double* Gr;     // (N+1) x 2 x 2
+    wcqp::GPtr<const double> Gr;     // (N+1) x 2 x 2   (GPtr: the struct also travels inside TickDev, which kernels read from device memory)
     double Gx[4], Gu[4], S0[4];
     double feas_tol, hull_tol;
     int N;
@@ -23,8 +24,12 @@ struct MpcDeviceConsts {
 
 #if defined(__HIPCC__)
 // candidate 0: no row; 1..8: single row e = id-1; 9..36: row pairs (e < f)
-__device__ const unsigned char kPairE[28] = {0,0,0,0,0,0,0, 1,1,1,1,1,1, 2,2,2,2,2, 3,3,3,3, 4,4,4, 5,5, 6};
-__device__ const unsigned char kPairF[28] = {1,2,3,4,5,6,7, 2,3,4,5,6,7, 3,4,5,6,7, 4,5,6,7, 5,6,7, 6,7, 7};
+// pair k (0..27) = rows (e < f) in the order {0,1},{0,2},...,{6,7}; four bits per entry, packed into literals: a table in memory
+// would be a global load, and where the MPC rides in the shadow of the IK's Jacobian loads (ik4.hip) vmcnt's in-order
+// retirement makes such a load wait for every Jacobian
+//   E = 0,0,0,0,0,0,0, 1,1,1,1,1,1, 2,2,2,2,2, 3,3,3,3, 4,4,4, 5,5, 6      F = 1,2,3,4,5,6,7, 2,3,4,5,6,7, 3,4,5,6,7, 4,5,6,7, 5,6,7, 6,7, 7
+__device__ __forceinline__ int pair_e(int k) { return (int)(((k < 16 ? 0x2221111110000000ull : 0x655444333322ull) >> (4 * (k & 15))) & 7ull); }
+__device__ __forceinline__ int pair_f(int k) { return (int)(((k < 16 ? 0x5437654327654321ull : 0x776765765476ull) >> (4 * (k & 15))) & 7ull); }
 constexpr int kNumCand = 1 + 8 + 28;
 
 // One DPP move of both halves of a double inside a row of 16 lanes (= one instance here).
@@ -49,7 +54,7 @@ struct MpcLoads {
 };
 __device__ __forceinline__ void mpc_window_loads(const MpcDeviceConsts& c, int t, const double2* __restrict__ rp, int ref_len, MpcLoads& L)
 {
-    const double2* gp = reinterpret_cast<const double2*>(c.Gr);
+    const double2* gp = reinterpret_cast<const double2*>(c.Gr.get());
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = t + k * kLanesPerInstance;
@@ -96,7 +101,7 @@ __device__ __forceinline__ void mpc_row_partial_lds(const MpcDeviceConsts& c, in
 }
 // stages 64 .. N of a horizon longer than one pass (the shipped controllerHorizon: N = 200), loaded on the spot
 __device__ __forceinline__ void mpc_row_extra_passes(const MpcDeviceConsts& c, int t, const double2* __restrict__ rp, int ref_len, double& ux, double& uy) {
-    const double2* gp = reinterpret_cast<const double2*>(c.Gr);
+    const double2* gp = reinterpret_cast<const double2*>(c.Gr.get());
     for (int base = 4 * kLanesPerInstance; base <= c.N; base += 4 * kLanesPerInstance) {
         double2 r[4], g0[4], g1[4];
 #pragma unroll
@@ -140,7 +145,7 @@ __device__ __forceinline__ void mpc_row_solve(const MpcDeviceConsts& c, int t, l
                                               double& u0x, double& u0y, int& status, unsigned& active, double& margin_out)
 {
     // ---- u0_unc = sum_i Gr_i r_i + Gx x0 + Gu u_prev ---------------------------------
-    const double2* gp = reinterpret_cast<const double2*>(c.Gr);
+    const double2* gp = reinterpret_cast<const double2*>(c.Gr.get());
     double ux = 0.0, uy = 0.0;
     // 64 stages per pass: the four reference loads of a lane (stages t, t+16, t+32, t+48) are
     // issued back to back before any is consumed, so one HBM round trip covers the whole window
@@ -212,7 +217,7 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
     for (int id = t; id < kNumCand; id += kLanesPerInstance) {
         int e = -1, f = -1;
         if (id >= 1 && id <= 8) e = id - 1;
-        else if (id > 8) { e = kPairE[id - 9]; f = kPairF[id - 9]; }
+        else if (id > 8) { e = pair_e(id - 9); f = pair_f(id - 9); }
         if (e >= nc || f >= nc) continue;
         double px = ux, py = uy, cost = 0.0;
         unsigned mask = 0;

@@ -88,6 +88,9 @@ int dev_alloc(wcqp_tick_s* h, T** out, size_t count) {
     return WCQP_OK;
 }
 
+template <typename T>
+int dev_alloc(wcqp_tick_s* h, wcqp::GPtr<T>* out, size_t count) { return dev_alloc(h, &out->p, count); }
+
 // one launch sequence of n_inner ticks (n_inner > 1: the fused base-eliminated kernel without per-tick kinematics only) with
 // the given phase (which copy of the tick index it reads: see TickDev::tick2)
 int enqueue_tick(wcqp_tick_s* h, int phase, hipStream_t s, int n_inner = 1, int skip_last_mpc = 0) {
@@ -254,7 +257,7 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     TickDev& d = h->d;
     const size_t B = (size_t)d.batch;
     WCQP_HIP_TRY(hipDeviceSynchronize());
-#define UP_(dst, src, n) WCQP_HIP_TRY(hipMemcpy((void*)(dst), (src), (n), hipMemcpyHostToDevice))
+#define UP_(dst, src, n) WCQP_HIP_TRY(hipMemcpy(const_cast<void*>(static_cast<const void*>(dst)), (src), (n), hipMemcpyHostToDevice))
     UP_(d.ref_traj, in->ref_traj, B * d.traj_len * 16);
     UP_(d.phase0, in->phase0, B * 4); UP_(d.swing_twist, in->swing_twist, B * 48);
     if (d.skew) {
@@ -273,7 +276,7 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     if (h->kin) {
         std::vector<double> h0(B);
         for (size_t i = 0; i < B; ++i) h0[i] = in->state0[i * kStateLen + 68];       // desired CoM height = the initial one
-        WCQP_HIP_TRY(hipMemcpy((void*)d.com_h0, h0.data(), B * 8, hipMemcpyHostToDevice));
+        WCQP_HIP_TRY(hipMemcpy(const_cast<double*>(d.com_h0.get()), h0.data(), B * 8, hipMemcpyHostToDevice));
     } else {
         UP_(d.hull_tab_A, in->hull_tab_A, B * 3 * 128); UP_(d.hull_tab_b, in->hull_tab_b, B * 3 * 64); UP_(d.hull_tab_nc, in->hull_tab_nc, B * 3 * 4);
         UP_(h->J_left, in->J_left, B * 6 * 29 * 8); UP_(h->J_right, in->J_right, B * 6 * 29 * 8);
@@ -283,8 +286,8 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     if (h->kin) {
         // setConvexHullConstraint (...PredictiveController.cpp:364-435) for the three contact pairs, from the DESIRED foot
         // poses just uploaded (the planned footsteps, WalkingModule.cpp:609-613): the MPC of a tick selects its rows by the pair
-        const int rch = wcqp::hull_tables_from_state((int)B, h->p.foot_rect, d.state, kStateLen, const_cast<double*>(d.hull_tab_A),
-                                                     const_cast<double*>(d.hull_tab_b), const_cast<int*>(d.hull_tab_nc), nullptr);
+        const int rch = wcqp::hull_tables_from_state((int)B, h->p.foot_rect, d.state, kStateLen, const_cast<double*>(d.hull_tab_A.get()),
+                                                     const_cast<double*>(d.hull_tab_b.get()), const_cast<int*>(d.hull_tab_nc.get()), nullptr);
         if (rch != WCQP_OK) return rch;
         WCQP_HIP_TRY(hipDeviceSynchronize());
     }
@@ -379,7 +382,7 @@ int wcqp_tick_splice_reference(wcqp_tick_t h, int32_t from_tick, int32_t n_stage
     if (from_tick < h->ticks_enqueued || (long)from_tick + n_stages > (long)d.traj_len) return WCQP_E_INVALID;
     // strided copy: row i of the tail goes to stages [from_tick, from_tick + n_stages) of instance i, in stream order
     // behind the ticks already enqueued (the trajectory pointer the kernels - and any captured graph - hold does not change)
-    WCQP_HIP_TRY(hipMemcpy2DAsync(const_cast<double*>(d.ref_traj) + (size_t)from_tick * 2, (size_t)d.traj_len * 16, ref_tail, (size_t)n_stages * 16,
+    WCQP_HIP_TRY(hipMemcpy2DAsync(const_cast<double*>(d.ref_traj.get()) + (size_t)from_tick * 2, (size_t)d.traj_len * 16, ref_tail, (size_t)n_stages * 16,
                                   (size_t)n_stages * 16, (size_t)d.batch, hipMemcpyHostToDevice, (hipStream_t)stream));
     return WCQP_OK;
 }

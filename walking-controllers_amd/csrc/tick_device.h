@@ -17,17 +17,17 @@ constexpr int kStateLen = WCQP_IK_STATE_LEN;
 
 struct TickDev {
     // per-instance constants
-    const double* ref_traj; const double* hull_tab_A; const double* hull_tab_b; const int* hull_tab_nc;
-    const int* phase0; const double* swing_twist;
+    wcqp::GPtr<const double> ref_traj; wcqp::GPtr<const double> hull_tab_A; wcqp::GPtr<const double> hull_tab_b; wcqp::GPtr<const int> hull_tab_nc;
+    wcqp::GPtr<const int> phase0; wcqp::GPtr<const double> swing_twist;
     // per-instance state
-    double *dcm, *com, *zmp_meas, *u_prev, *u0, *c_ref, *v_ref, *p_star, *v_star_prev, *v_ref_prev;
-    double *q_des, *dq_prev, *dq, *state;
-    int *sel, *mpc_status, *ik_status;     // sel: contact pair of the CURRENT tick (0 left, 1 right, 2 both)
-    long long *mpc_fail, *ik_fail;
-    int* tick2;         // ticks completed, kept TWICE: the kernels of a tick read tick2[phase], the last of them writes
+    wcqp::GPtr<double> dcm, com, zmp_meas, u_prev, u0, c_ref, v_ref, p_star, v_star_prev, v_ref_prev;
+    wcqp::GPtr<double> q_des, dq_prev, dq, state;
+    wcqp::GPtr<int> sel, mpc_status, ik_status;     // sel: contact pair of the CURRENT tick (0 left, 1 right, 2 both)
+    wcqp::GPtr<long long> mpc_fail, ik_fail;
+    wcqp::GPtr<int> tick2;         // ticks completed, kept TWICE: the kernels of a tick read tick2[phase], the last of them writes
     int phase;          // tick2[1 - phase] = tick + 1 and the next tick runs with the other phase (a host-side
                         // parity: nobody reads the word that is being written, so one kernel may do both)
-    double *u0_log, *dq_log;
+    wcqp::GPtr<double> u0_log, dq_log;
     // scalars
     int batch, first, traj_len, log_ticks, step_ticks, ds_ticks;
     double omega, a, b, dT, k_com, k_zmp, noise, com_height;
@@ -39,28 +39,28 @@ struct TickDev {
     // state (WalkingModule.cpp:715, 373-376), not the plant's, and the desired height is the
     // instance's initial one
     int kin_mode;
-    const double* com_h0;     // [B]
+    wcqp::GPtr<const double> com_h0;     // [B]
     // IK hot start (qpOASES SQProblem::hotstart, WM/src/WalkingQPInverseKinematics_qpOASES.cpp:316-318): the previous
     // tick's active bounds (the kernel's own active_lower / active_upper words, 8 B per robot) are tried first
     int hot_start;
-    long long *hot_try, *hot_hit;     // [B] ticks on which a previous active set was tried / accepted
+    wcqp::GPtr<long long> hot_try, hot_hit;     // [B] ticks on which a previous active set was tried / accepted
     // ---- the SKEWED tick of the base-eliminated fused kernel (ik4.hip): the launch of tick t carries IK(t) and MPC(t+1).
     // The MPC chain MPC(t) -> ZMP-CoM law -> LIPM plant -> MPC(t+1) does not depend on the IK, so the MPC of the NEXT tick
     // runs in the shadow of this tick's Jacobian loads; its outputs reach IK(t+1) through a hand-off record.
     int skew;
-    double* mst;        // [B][2][8] state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (= measured ZMP), p_star,
+    wcqp::GPtr<double> mst;        // [B][2][8] state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (= measured ZMP), p_star,
                         //           v_star_prev, dcm, spare - one 64-byte record per axis, loaded as four 16-byte pieces
-    double* hand;       // [2][B][kHandLen] MPC(t) -> IK(t) at parity t & 1: p_star xy, v_star xy, com(t) xy, dcm(t) xy, mpc_ok, spare,
+    wcqp::GPtr<double> hand;       // [2][B][kHandLen] MPC(t) -> IK(t) at parity t & 1: p_star xy, v_star xy, com(t) xy, dcm(t) xy, mpc_ok, spare,
                         //           measured ZMP(t) xy (= the previous command), u0(t) xy   (com / dcm / ZMP: the plant at the START of
                         //           tick t; the last six entries feed the logger rows only)
-    double* live_A; double* live_b; int* live_nc; int* sel_built;     // one live hull row set per robot ([B][8][2], [B][8], [B])
+    wcqp::GPtr<double> live_A; wcqp::GPtr<double> live_b; wcqp::GPtr<int> live_nc; wcqp::GPtr<int> sel_built;     // one live hull row set per robot ([B][8][2], [B][8], [B])
                         //           and the contact pair it holds: copied from the robot's three-set table on a contact change, so
                         //           that the rows of a tick are loaded from a fixed address, without waiting for the contact pair
     // ---- compact kinematics -> IK hand-off (tick-internal): per robot one record per joint, [C lin3 | X] with X = the
     // joint's column of the ONE frame Jacobian it is on the path of (left foot 6, right foot 6, neck angular 3), and the
     // three vectors p_frame - p_base that make up the base blocks.  cmask*: joints on the path of the left sole / right sole / neck.
     int compact;
-    const double* jcomp; unsigned cmaskL, cmaskR, cmaskN; int cstride, coff_d;
+    wcqp::GPtr<const double> jcomp; unsigned cmaskL, cmaskR, cmaskN; int cstride, coff_d;
     // ---- kinematics FUSED into the tick kernel (ik4.hip, JSRC = 2): no kinematics launch, no Jacobian hand-off through memory
     // at all - the wave that solves a robot's IK first evaluates its forward kinematics and Jacobian columns, 16 lanes per
     // robot, two joints per lane - and the kernel can then walk through many ticks per launch, like the constant-Jacobian form.
@@ -68,12 +68,12 @@ struct TickDev {
     // mass | four ints: the joint's pointer-jumping links of rounds 0..2, the last joint of its subtree | pad; then [3][12]
     // attached frames R 9 | p 3; then root_com 3, root_mass, three ints: the joints the frames are attached to.
     int kin_fused, kin_rounds;
-    const double* kin_tab;
+    wcqp::GPtr<const double> kin_tab;
     // ---- logger rows (wcqp_tick_params.logger_ticks): the 53 values WalkingModule hands its logger per tick
     // (WM/src/WalkingModule.cpp:800-810, column names :1231-1250), kept for the first logger_ticks ticks
-    double* log_rows;   // [logger_ticks][B][kLoggerCols]
+    wcqp::GPtr<double> log_rows;   // [logger_ticks][B][kLoggerCols]
     int logger_ticks;
-    unsigned long long* stamps;     // diagnostic builds (-DWCQP_TICK_STAMPS): [workgroups][16] s_memtime at the phase boundaries; else NULL
+    wcqp::GPtr<unsigned long long> stamps;     // diagnostic builds (-DWCQP_TICK_STAMPS): [workgroups][16] s_memtime at the phase boundaries; else NULL
 };
 constexpr int kHandLen = 14;
 constexpr int kLoggerCols = 53;
@@ -221,16 +221,16 @@ struct TickMpcRegs {
 // GAINS_LDS: the gain blocks Gr are read from a copy in LDS at the time of use (gr_lds), not loaded into registers here
 template <bool GAINS_LDS = false>
 __device__ __forceinline__ void tick_mpc_issue(const TickDev& d, int j, long inst, int t, TickMpcRegs& R) {
-    const double2* rp = reinterpret_cast<const double2*>(d.ref_traj) + inst * d.traj_len + t;
+    const double2* rp = reinterpret_cast<const double2*>(d.ref_traj.get()) + inst * d.traj_len + t;
     R.phase0 = d.phase0[inst];
     R.built = d.sel_built[inst];
-    const double2* sp = reinterpret_cast<const double2*>(d.mst + (inst * 2 + (j & 1)) * 8);
+    const double2* sp = reinterpret_cast<const double2*>(d.mst.get() + (inst * 2 + (j & 1)) * 8);
     R.s01 = sp[0]; R.s23 = sp[1]; R.s45 = sp[2]; R.s67 = sp[3];
     if constexpr (GAINS_LDS) wcqp_mpc::mpc_window_loads_ref_only(d.mpc, j, rp, d.horizon + 1, R.L);
     else wcqp_mpc::mpc_window_loads(d.mpc, j, rp, d.horizon + 1, R.L);
     R.nc = d.live_nc[inst];
     const int jr = j & 7;
-    R.ha = reinterpret_cast<const double2*>(d.live_A)[inst * WCQP_HULL_ROWS + jr];
+    R.ha = reinterpret_cast<const double2*>(d.live_A.get())[inst * WCQP_HULL_ROWS + jr];
     R.hb = d.live_b[inst * WCQP_HULL_ROWS + jr];
 }
 // tick_mpc_finish = tick_mpc_partial (this lane's share of u0_unc from the loaded window: the window registers die here) +
@@ -240,7 +240,7 @@ __device__ __forceinline__ void tick_mpc_partial(const TickDev& d, int j, long i
     if constexpr (GAINS_LDS) wcqp_mpc::mpc_row_partial_lds(d.mpc, j, R.L, gr_lds, ux, uy);
     else wcqp_mpc::mpc_row_partial(d.mpc, j, R.L, ux, uy);
     if (d.horizon >= 4 * wcqp_mpc::kLanesPerInstance)
-        wcqp_mpc::mpc_row_extra_passes(d.mpc, j, reinterpret_cast<const double2*>(d.ref_traj) + inst * d.traj_len + t, d.horizon + 1, ux, uy);
+        wcqp_mpc::mpc_row_extra_passes(d.mpc, j, reinterpret_cast<const double2*>(d.ref_traj.get()) + inst * d.traj_len + t, d.horizon + 1, ux, uy);
 }
 // r0: stage 0 of the window (the reference DCM of tick t; meaningful on lane 0)
 __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double2 r0, double ux, double uy,
@@ -255,7 +255,7 @@ __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, lo
             double* lb = d.live_b + inst * WCQP_HULL_ROWS;
             const long hset = inst * 3 + code;
             if (j < WCQP_HULL_ROWS) {
-                reinterpret_cast<double2*>(lA)[j] = reinterpret_cast<const double2*>(d.hull_tab_A)[hset * WCQP_HULL_ROWS + j];
+                reinterpret_cast<double2*>(lA)[j] = reinterpret_cast<const double2*>(d.hull_tab_A.get())[hset * WCQP_HULL_ROWS + j];
                 lb[j] = d.hull_tab_b[hset * WCQP_HULL_ROWS + j];
             }
             if (j == 0) { d.live_nc[inst] = d.hull_tab_nc[hset]; d.sel_built[inst] = code; }
@@ -266,8 +266,11 @@ __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, lo
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         R.nc = d.live_nc[inst];
         const int jr = j & 7;
-        R.ha = reinterpret_cast<const double2*>(d.live_A)[inst * WCQP_HULL_ROWS + jr];
+        R.ha = reinterpret_cast<const double2*>(d.live_A.get())[inst * WCQP_HULL_ROWS + jr];
         R.hb = d.live_b[inst * WCQP_HULL_ROWS + jr];
+        // ... and wait for them HERE, on the rare path: left to the compiler the wait lands behind the join, where it must assume
+        // that the row registers were loaded last - behind the IK's Jacobian loads - and drains those on every tick
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     }
     // ---- the condensed MPC (mpc_device.h): x0 = measured DCM, u_prev = previous output (MPCSolver.cpp:244-245)
     {
@@ -297,7 +300,7 @@ __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, lo
         // synthetic plant: LIPM with a bounded disturbance
         const double com1 = com + d.dT * (-d.omega * (com - xi));
         const double xi1 = d.a * xi + d.b * u + d.noise * disturbance(d.seed, (unsigned long long)(d.first + inst), t, ax);
-        double2* sp = reinterpret_cast<double2*>(d.mst + (inst * 2 + ax) * 8);
+        double2* sp = reinterpret_cast<double2*>(d.mst.get() + (inst * 2 + ax) * 8);
         sp[0] = make_double2(c_ref, vr); sp[1] = make_double2(com1, u); sp[2] = make_double2(p_star, v); sp[3] = make_double2(xi1, 0.0);
         // hand-off to the IK of tick t (desired CoM position / velocity, WalkingModule.cpp:686-695) + the plant state at the start of tick t
         double* hd = d.hand + ((size_t)(t & 1) * d.batch + inst) * kHandLen;
