@@ -298,8 +298,29 @@ def main():
         for i in range(K):
             step(i)
         barrier()
-    for i in range(args.warmup):
-        step(i)
+    def fill_record(r, i):
+        """Argument record of step i: input set i % K, output buffers i % P."""
+        d, k = sets[i % K], i % P
+        o, m, q_ = optr[k], d["_mpc"], d["_ik"]
+        r.x0, r.ref, r.ref_len, r.u_prev, r.hull_A, r.hull_b, r.hull_nc = m[0], m[1], N1, m[2], m[3], m[4], m[5]
+        r.u0, r.mpc_status, r.mpc_active, r.mpc_margin, r.mpc_stream = o["u0"], o["mstat"], o["mact"], o["mmar"], sptr[k][1] or None
+        r.J_left, r.J_right, r.J_neck, r.J_com, r.q, r.state = q_
+        r.dq, r.ik_status, r.active_lower, r.active_upper, r.foot_err, r.iters = o["dq"], o["istat"], o["ilo"], o["iup"], None, o["iit"]
+        r.ik_stream = sptr[k][0] or None
+
+    # the W warm-up steps, in the form the timed steps take: in plan mode as a plan of their own (one launch of qp_plan_kernel -
+    # otherwise the timed launch would be the first launch of that kernel in the process)
+    if use_plan and not exch and args.warmup > 0 and (not args.plan_queue or args.warmup <= P):
+        wrecs = (wca.capi.QpStep * args.warmup)()
+        for i in range(args.warmup):
+            fill_record(wrecs[i], i)
+        wplan = wca.capi.QpPlan(mpc, ik, B, wrecs, ways=plan_ways)
+        wplan.enqueue(sp)
+        barrier()
+        wplan.close()
+    else:
+        for i in range(args.warmup):
+            step(i)
     barrier()
     # the argument records of the timed steps (set-up): step i = the MPC and the IK call of step(i), handed to the
     # library in ONE host call (wcqp_qp_enqueue_steps) - through ctypes a launch costs the host ~4.4 us, two kernels of 5
@@ -308,15 +329,7 @@ def main():
     if not exch:
         recs = (wca.capi.QpStep * args.steps)()
         for n in range(args.steps):
-            i = args.warmup + n
-            d, k = sets[i % K], i % P
-            o, m, q_ = optr[k], d["_mpc"], d["_ik"]
-            r = recs[n]
-            r.x0, r.ref, r.ref_len, r.u_prev, r.hull_A, r.hull_b, r.hull_nc = m[0], m[1], N1, m[2], m[3], m[4], m[5]
-            r.u0, r.mpc_status, r.mpc_active, r.mpc_margin, r.mpc_stream = o["u0"], o["mstat"], o["mact"], o["mmar"], sptr[k][1] or None
-            r.J_left, r.J_right, r.J_neck, r.J_com, r.q, r.state = q_
-            r.dq, r.ik_status, r.active_lower, r.active_upper, r.foot_err, r.iters = o["dq"], o["istat"], o["ilo"], o["iup"], None, o["iit"]
-            r.ik_stream = sptr[k][0] or None
+            fill_record(recs[n], args.warmup + n)
     # --step-graph: the K timed steps as ONE hipGraph - P parallel chains of one-launch steps (pipeline p's steps in order on
     # its stream, the chains forked from and joined into the capture stream), captured from the very wcqp_qp_enqueue_steps
     # call the launch-by-launch form makes; set-up: capture, instantiate, one replay (the first launch of a graph uploads

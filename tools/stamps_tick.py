@@ -16,7 +16,10 @@ if kin_mode:
     kb = S.synth_walk_kin_batch(B)
     poses = kin.jacobians_host(kb["base"], kb["q"], state=np.zeros((B, 87)))["state"]
     d = S.synth_walk_batch(B, T, poses, kb)
-    ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=S.WALK_VMAX, joint_reg_rad=np.deg2rad(S.WALK_POSTURE_DEG))
+    vmax = S.WALK_VMAX.copy() if hasattr(S.WALK_VMAX, "copy") else np.broadcast_to(S.WALK_VMAX, (23,)).copy()
+    if len(sys.argv) > 4:
+        vmax[:] = float(sys.argv[4])           # e.g. 5.0: no joint-velocity bound ever binds
+    ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, joint_reg_rad=np.deg2rad(S.WALK_POSTURE_DEG))
 else:
     kin, d = None, S.synth_tick_batch(B, T)
     ik = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.5)

@@ -43,9 +43,27 @@ __device__ __forceinline__ void frame_mul(const double* Ra, const double* pa, co
     for (int k = 0; k < 3; ++k) po[k] = pa[k] + d[k];
 }
 // local frame of a revolute joint: R0 * Rot(axis, q)   (Rodrigues)
+// sin and cos of a joint angle: Cody-Waite reduction by pi/2 in two FMA steps and the fdlibm kernels on |r| <= pi/4 (their
+// published minimax coefficients; < 1 ulp each).  Joint angles are a few radians at most: the reduction's error is
+// |k| x 2^-107, nothing the Payne-Hanek branch of ocml's sincos (154 VALU instructions and two branches per call) would add to.
+__device__ __forceinline__ void joint_sincos(double x, double& sn, double& cs) {
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double s = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+    const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * pc);
+    const int n = (int)k & 3;
+    const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;
+    sn = (n & 2) ? -a : a;
+    cs = ((n + 1) & 2) ? -b : b;
+}
 __device__ __forceinline__ void joint_rotation(const double* R0, const double* ax, double q, double* Ra) {
     double sn, cs;
-    sincos(q, &sn, &cs);
+    joint_sincos(q, sn, cs);
     const double v = 1.0 - cs;
     const double Rq[9] = {cs + v * ax[0] * ax[0],         v * ax[0] * ax[1] - sn * ax[2], v * ax[0] * ax[2] + sn * ax[1],
                           v * ax[1] * ax[0] + sn * ax[2], cs + v * ax[1] * ax[1],         v * ax[1] * ax[2] - sn * ax[0],
