@@ -179,3 +179,28 @@ def test_compact_jacobian_layout_of_the_icub_shaped_tree(wca):
     for j in range(23):
         desc = [k for k in range(23) if (path(k) >> j) & 1]
         assert desc == list(range(j, j + len(desc)))
+
+
+def test_kernels_hold_no_flat_memory_instructions(wca, tmp_path):
+    """Every global-memory access of the shipped kernels is a global_* instruction.  A pointer that a kernel reads out of a
+    record in device memory (the tick's TickDev, the plan's step records) is generic unless it is marked (csrc/gptr.h), and an
+    access through a generic pointer is a flat_* instruction: it counts on vmcnt AND lgkmcnt and forces full drains, which
+    silently undid the 'state block first, Jacobians stay in flight' order of the walking kernels for most of round 3
+    (DESIGN.md 4.4).  Checked on the device code inside the built objects (no GPU needed)."""
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    build = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "walking-controllers_amd", "csrc", "build")
+    checked = 0
+    for name in ("mpc", "ik2", "ik3", "ik4", "tick", "hull", "kin"):
+        obj = os.path.join(build, name + ".hip.o")
+        assert os.path.exists(obj), obj
+        fat, dev = str(tmp_path / (name + ".fatbin")), str(tmp_path / (name + ".co"))
+        subprocess.run([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, str(tmp_path / "unused.o")], check=True)
+        subprocess.run([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--input=" + fat, "--output=" + dev], check=True)
+        asm = subprocess.run([llvm + "/llvm-objdump", "-d", dev], check=True, capture_output=True, text=True).stdout
+        assert len(re.findall(r"\bglobal_(?:load|store)", asm)) > 0, name
+        flat = re.findall(r"\bflat_(?:load|store|atomic)\w*", asm)
+        assert not flat, (name, len(flat), sorted(set(flat)))
+        checked += 1
+    assert checked == 7
