@@ -168,7 +168,23 @@ def main():
     set_bytes = B * (mpc_bytes - 16 + IK_BYTES_PER_QP - 184)
     # (> 1 GiB in total: with 320 MB - 14 sets at 4096 robots - the PMC passes of round 3 showed the one-launch plan getting 31 % of
     # its input bytes from the 256 MiB Infinity Cache, HBM traffic 0.69 x the algorithmic bytes; launch by launch it was 1.04 x)
-    K = args.input_sets if args.input_sets > 0 else int(min(64, max(2, -(-(1 << 30) // set_bytes))))
+    # AND far apart in the plan's own order: a wavefront of a 4-way plan comes back to input set k after K / gcd(K, ways) of its
+    # records, and in that time the card's resident wavefronts have read that many x 2048 x 25 KB.  With 3 sets of 400 MB (65536
+    # robots: 1.2 GB "cold" by the first rule) that is 154 MB - the sets were coming out of the Infinity Cache, and the kernel showed
+    # 0.65 of the roofline where it is 0.55 with inputs of its own for every step (profiles/r03_plan_queue_distinct_inputs.txt).
+    # At least 13 sets, their number coprime with the ways.  The work-queue form orders the units robot-group-major - the records of
+    # a robot group follow each other within microseconds - so there EVERY step gets input arrays of its own.
+    import math
+    if args.input_sets > 0:
+        K = args.input_sets
+    elif args.plan_queue and args.workload == "qp":
+        K = args.steps + args.warmup
+        if K * set_bytes > 96e9:
+            raise SystemExit("bench.py: --plan-queue 1 gives every step input arrays of its own; %d steps x %.0f MB do not fit" % (K, set_bytes / 1e6))
+    else:
+        K = int(max(13, min(64, -(-(1 << 30) // set_bytes))))
+        while math.gcd(K, max(1, args.plan_ways)) != 1:
+            K += 1
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
     use_plan = (args.plan_ways > 0 and not (args.exchange and dist is not None) and args.streams in (0, 1) and args.ik_jac == "mixed"
                 and not args.step_graph)
@@ -518,7 +534,7 @@ def main():
             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": plan_ms * n_plan, "steps_per_launch": n_plan, "avg_ms_per_step": plan_ms,
             "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B * n_plan,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total, 4 x the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6, K * set_bytes / 1e9),
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total; a wavefront returns to a set after %d of its records)" % (K, set_bytes / 1e6, K * set_bytes / 1e9, K // math.gcd(K, max(1, plan_ways if use_plan else 1))),
             "frac_resident_inputs": ((IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS) if plan_ms_res else None, "avg_ms_per_step_resident_inputs": plan_ms_res,
             "timed_region": {"achieved": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9,
                              "frac": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
@@ -527,7 +543,7 @@ def main():
             "achieved": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": pair_ms, "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total, 4 x the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6, K * set_bytes / 1e9),
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total; a wavefront returns to a set after %d of its records)" % (K, set_bytes / 1e6, K * set_bytes / 1e9, K // math.gcd(K, max(1, plan_ways if use_plan else 1))),
             "frac_resident_inputs": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": pair_ms_res,
             # `frac` prices ONE launch running alone (back-to-back launches of the kernel on one stream: what `rocprofv3 --stats`
             # reports for a --pipelines 1 run); with P batches in flight the launches overlap, each takes longer, and the
@@ -538,7 +554,7 @@ def main():
             "bound": "hbm", "kernel": ik_kernel,
             "achieved": ik_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ik_gbs / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": ik_ms, "algorithmic_bytes_per_launch": IK_BYTES_PER_QP * B,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total, 4 x the 256 MiB Infinity Cache)" % (K, set_bytes / 1e6, K * set_bytes / 1e9),
+            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total; a wavefront returns to a set after %d of its records)" % (K, set_bytes / 1e6, K * set_bytes / 1e9, K // math.gcd(K, max(1, plan_ways if use_plan else 1))),
             "frac_resident_inputs": IK_BYTES_PER_QP * B / (ik_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": ik_ms_res,
         }),
         "kernels": {

@@ -295,7 +295,7 @@ int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch,
  * ... (two ways fill both wave slots of every SIMD at the BASELINE batch of 4096).  Records of DIFFERENT ways run
  * concurrently: they must not share output arrays (give each way its own, like the pipelines of separate streams).
  * ways = 0 is the WORK-QUEUE form: the launch has as many wavefronts as are resident at once (2 per SIMD), and each takes the
- * next (record, robot group) unit - record-major - from a device-side queue when it is done with one, so that no wave slot
+ * next (record, robot group) unit - robot-group-major - from a device-side queue when it is done with one, so that no wave slot
  * idles while another wavefront still has records left (the tail of the fixed ways).  Any two records may then be in flight
  * together and in any order: NO two records of the plan may share an output array.  The queue is re-armed by the launch itself;
  * launches of ONE plan must be ordered (one stream at a time), different plans are independent.  Every

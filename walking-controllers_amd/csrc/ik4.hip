@@ -1640,7 +1640,9 @@ void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcq
 {
     __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
     // ways > 0: workgroup (way, robot group) walks through records way, way + ways, ... of its group.
-    // ways = 0, work queues: unit u = (record u / groups, robot group u % groups), record-major.  kPlanQueues ticket counters,
+    // ways = 0, work queues: unit u = (robot group u / n_steps, record u % n_steps), GROUP-major: the resident waves then work inside a
+    // window of a few dozen robot groups (record-major at 65536 robots every unit of a wave lies 11 MB further on in each of the
+    // twelve input arrays - a new page per array per record: 15 % slower than the fixed ways; group-major it is on a par).  kPlanQueues ticket counters,
     // kPlanQueueStride bytes apart (one counter serves ~8e7 tickets/s - measured: every wave behind ONE counter ran at half the
     // rate of the fixed ways, at every batch size - and the launch needs 1.5e8); ticket k of queue q is unit k kPlanQueues + q.
     // A wave draws from its home queue, asking for the next ticket behind the record's loads (ik4_body; the answer is needed at the
@@ -1668,7 +1670,7 @@ void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcq
     int r = (int)blockIdx.x / groups, blk = (int)blockIdx.x % groups;
     if (dynamic) {
         const unsigned u = draw();
-        r = (int)(u / (unsigned)groups); blk = (int)(u % (unsigned)groups);
+        r = u < total ? (int)(u % (unsigned)n_steps) : n_steps; blk = u < total ? (int)(u / (unsigned)n_steps) : 0;
     }
 #pragma unroll 1
     while (r < n_steps) {
@@ -1686,7 +1688,7 @@ void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcq
         if (dynamic) {
             unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)m.ticket) * wcqp_ik::kPlanQueues + home;
             if (u >= total) { home = (home + 1u) % wcqp_ik::kPlanQueues; u = draw(); }
-            r = (int)(u / (unsigned)groups); blk = (int)(u % (unsigned)groups);
+            r = u < total ? (int)(u % (unsigned)n_steps) : n_steps; blk = u < total ? (int)(u / (unsigned)n_steps) : 0;
         } else {
             r += ways;
         }
