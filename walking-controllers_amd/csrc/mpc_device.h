@@ -129,6 +129,10 @@ __device__ __forceinline__ void mpc_row_add_state(const MpcDeviceConsts& c, doub
 // The arithmetic of one MPC QP on the 16 lanes of a DPP row from loaded operands: `uxy_in` = this lane's partial sum of
 // u0_unc (the gain-weighted reference stages and, on lane 0, the x0 / u_prev terms), (nc, rax, ray, rb) = row count and
 // this lane's hull row.  All 64 lanes of the wave must call it together (wave-level early out, LDS fences).
+// a . u - b of a hull row, with the FMAs spelled out: left to -ffp-contract the product a_x u_x is sometimes shared with another
+// expression (unfused) and sometimes not, by what surrounds the inlined code - and the kernels that inline this (mpc_condensed_kernel,
+// qp_pair_kernel, qp_plan_kernel, the tick kernels) must agree bit for bit
+__device__ __forceinline__ double row_res(double ax, double ay, double b, double x, double y) { return fma(ay, y, fma(ax, x, -b)); }
 __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, double ux, double uy,
                                                int nc, double rax, double ray, double rb, double (*s_hull)[4],
                                                double& u0x, double& u0y, int& status, unsigned& active, double& margin_out);
@@ -191,7 +195,7 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
     nc = nc < 0 ? 0 : (nc > WCQP_HULL_ROWS ? WCQP_HULL_ROWS : nc);
     double rn = 0.0;                                     // norm of this lane's own hull row (lanes 0..7)
     if (t < WCQP_HULL_ROWS) {
-        rn = sqrt(rax * rax + ray * ray);
+        rn = sqrt(fma(ray, ray, rax * rax));
         s_hull[t][0] = rax; s_hull[t][1] = ray; s_hull[t][2] = rb; s_hull[t][3] = rn;
     }
     // butterfly over the row (DPP, no LDS-pipe round trips): every lane ends with the same sum
@@ -210,7 +214,7 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
     // already satisfies its hull rows, candidate 0 wins by construction (cost 0, lowest id) and the
     // 37-candidate enumeration is skipped.  Same feasibility test as the enumeration applies to
     // candidate 0, so the result is identical either way.
-    const bool row_violated = t < nc && (rax * ux + ray * uy - rb) > c.feas_tol;
+    const bool row_violated = t < nc && row_res(rax, ray, rb, ux, uy) > c.feas_tol;
     if (__ballot(row_violated) == 0ull) {
         best_cost = 0.0; best_id = 0;
     } else
@@ -226,7 +230,7 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
             const double aex = s_hull[e][0], aey = s_hull[e][1];
             const double sex = s00 * aex + s01 * aey, sey = s10 * aex + s11 * aey;   // Sigma0 a_e
             const double ree = aex * sex + aey * sey;
-            const double re  = aex * ux + aey * uy - s_hull[e][2];
+            const double re  = row_res(aex, aey, s_hull[e][2], ux, uy);
             mask = 1u << e;
             if (f < 0) {
                 ok = ree > 0.0;
@@ -238,7 +242,7 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
                 const double sfx = s00 * afx + s01 * afy, sfy = s10 * afx + s11 * afy;
                 const double rff = afx * sfx + afy * sfy;
                 const double ref_ = aex * sfx + aey * sfy;
-                const double rf  = afx * ux + afy * uy - s_hull[f][2];
+                const double rf  = row_res(afx, afy, s_hull[f][2], ux, uy);
                 const double det = ree * rff - ref_ * ref_;
                 ok = det > 1e-12 * ree * rff;                 // parallel rows have no vertex
                 const double idet = ok ? wcqp::fast_rcp(det) : 0.0;
@@ -250,7 +254,7 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
             }
         }
         for (int k = 0; k < nc; ++k) {
-            const double res = s_hull[k][0] * px + s_hull[k][1] * py - s_hull[k][2];
+            const double res = row_res(s_hull[k][0], s_hull[k][1], s_hull[k][2], px, py);
             ok = ok && (k == e || k == f || res <= c.feas_tol);
         }
         if (ok && (cost < best_cost || (cost == best_cost && id < best_id))) {
@@ -267,7 +271,7 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
 #undef WCQP_MIN_STEP
     // signed distance to the hull boundary (computeMargin semantics): every row lane evaluates its
     // own row, row-min by DPP
-    double margin = (t < nc && rn > 0.0) ? (rb - rax * best_x - ray * best_y) / rn : std::numeric_limits<double>::infinity();
+    double margin = (t < nc && rn > 0.0) ? -row_res(rax, ray, rb, best_x, best_y) / rn : std::numeric_limits<double>::infinity();
 #define WCQP_MARGIN_STEP(C) margin = fmin(margin, row_move<C>(margin));
     WCQP_ROW_STEPS(WCQP_MARGIN_STEP)
 #undef WCQP_MARGIN_STEP
