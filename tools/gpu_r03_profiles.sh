@@ -43,6 +43,8 @@ echo "pmc detail"
 cd $R
 python3 tools/pmc/summarize.py $O/pmc > $O/pmc_summary.json 2> $O/pmc_summary.err
 python3 tools/pmc/make_traffic.py $O/pmc_summary.json > $O/traffic.json 2> $O/traffic.err
+# the bench lines below quote roofline.traffic from profiles/traffic.json when its source hash is the current one: this run's own PMC passes
+[ -s $O/traffic.json ] && cp $O/traffic.json $R/profiles/traffic.json
 # bench lines (no profiler attached)
 timeout -k 10 400 python3 bench.py --steps 200 --warmup 20 > $O/bench_b4096.json 2> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench_b4096_driver.json 2>> $O/bench.err
