@@ -309,34 +309,48 @@ def qp_exact(H, g, Aeq, beq, Ain, bin_, tol=1e-11, max_iter=200, w0: Sequence[in
     bin_ = np.asarray(bin_, float).reshape(-1)
     meq = Aeq.shape[0]
     scale = np.maximum(1.0, np.linalg.norm(Ain, axis=1)) if Ain.size else np.ones(0)
-    out = _walk(H, g, Aeq, beq, Ain, bin_, scale, tol, max_iter, w0)
-    if out is None:
+    def by_goldfarb_idnani():
         if not qp_feasible(Aeq, beq, Ain, bin_):
             raise QPInfeasible("constraints admit no point")
         x, W, _ = _goldfarb_idnani(H, g, Aeq, beq, Ain, bin_, tol, max_iter)
         C = np.vstack([Aeq, Ain[W]]) if W else Aeq
         d = np.concatenate([beq, bin_[W]]) if W else beq
         x, lam = _kkt_solve(H, g, C, d)          # polish on the identified set
-        lam_eq, mu_w = lam[:meq], lam[meq:]
-    else:
-        x, lam_eq, mu_w, W = out
+        return x, lam[:meq], lam[meq:], W
+
+    def certificate(x, lam_eq, mu_w, W):
+        """None if (x, multipliers) is a KKT point, else what is wrong with it."""
+        mu = np.zeros(Ain.shape[0])
+        if W:
+            mu[W] = mu_w
+        gs = max(1.0, np.abs(g).max(), np.abs(H @ x).max())
+        stat = H @ x + g + Aeq.T @ lam_eq + (Ain.T @ mu if Ain.size else 0.0)
+        if np.abs(stat).max() > 1e-7 * gs:
+            return f"stationarity residual {np.abs(stat).max():.3e}"
+        if meq and np.abs(Aeq @ x - beq).max() > 1e-8 * max(1.0, np.abs(beq).max()):
+            return "equality residual"
+        if Ain.size:
+            if ((Ain @ x - bin_) / scale).max() > 1e-8:
+                return "primal infeasible"
+            if mu.min() < -1e-8 * gs:
+                return "dual infeasible"
+        return None
+
+    out = _walk(H, g, Aeq, beq, Ain, bin_, scale, tol, max_iter, w0)
+    why = None if out is None else certificate(*out)
+    if out is None or why is not None:
+        # the walk cycled, or ended on a working set whose KKT system is singular (an infeasible or degenerate instance: the
+        # least-squares point it returns is not stationary): the dual method decides - after the phase-1 feasibility check
+        out = by_goldfarb_idnani()
+        why = certificate(*out)
+        if why is not None:
+            if why == "primal infeasible" and not qp_feasible(Aeq, beq, Ain, bin_):
+                raise QPInfeasible("constraints admit no point")
+            raise QPOracleError(why)
+    x, lam_eq, mu_w, W = out
     mu = np.zeros(Ain.shape[0])
     if W:
         mu[W] = mu_w
-    # ---- KKT certificate -----------------------------------------------------------
-    gs = max(1.0, np.abs(g).max(), np.abs(H @ x).max())
-    stat = H @ x + g + Aeq.T @ lam_eq + (Ain.T @ mu if Ain.size else 0.0)
-    if np.abs(stat).max() > 1e-7 * gs:
-        raise QPOracleError(f"stationarity residual {np.abs(stat).max():.3e}")
-    if meq and np.abs(Aeq @ x - beq).max() > 1e-8 * max(1.0, np.abs(beq).max()):
-        raise QPOracleError("equality residual")
-    if Ain.size:
-        if ((Ain @ x - bin_) / scale).max() > 1e-8:
-            if not qp_feasible(Aeq, beq, Ain, bin_):
-                raise QPInfeasible("constraints admit no point")
-            raise QPOracleError("primal infeasible")
-        if mu.min() < -1e-8 * gs:
-            raise QPOracleError("dual infeasible")
     return x, lam_eq, mu, sorted(W)
 
 
