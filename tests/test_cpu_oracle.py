@@ -193,3 +193,14 @@ def test_c_oracle_is_clean_under_asan_ubsan():
     r = subprocess.run([os.path.join(root, "oracle", "_build", "selftest_asan")], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "mpc fail 0" in r.stdout and "ik form 0 fail 0" in r.stdout and "ik form 1 fail 0" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("seed,i,vmax", [(31010, 142, 0.2), (31010, 165, 0.2), (31012, 181, 0.15)])
+def test_exact_oracle_says_infeasible_when_its_walk_ends_on_a_singular_set(qs, wca, seed, i, vmax):
+    """Found by tools/fuzz_vs_oracle.py: on these infeasible instances the oracle's primal walk ends on a working set whose KKT
+    system is singular and returns a least-squares point that fails the certificate.  That used to surface as QPOracleError
+    ('could not certify') although the kernels answer WCQP_STATUS_INFEASIBLE; the certificate failure now falls back to the
+    phase-1 LP + Goldfarb-Idnani path, which says what the instance is."""
+    b = wca.synth.synth_ik_batch(256, seed=seed)
+    with pytest.raises(qs.QPInfeasible):
+        qs.ik_exact(qs.IKParams(v_max=vmax * np.ones(23)), qs.ik_inputs_from_batch(b, i), "qpoases")
