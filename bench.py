@@ -795,7 +795,8 @@ def bench_tick(args, wca, torch, dist, dev, world, rank, B, first):
                      "own_hbm_bytes_per_robot_tick": own_bytes, "frac_own": own_bytes * B / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "inputs": ("constant Jacobians, %.0f MB for the batch, re-read every tick: %s" % (4464 * B / 1e6, "they fit the 256 MiB Infinity Cache - this line is priced "
                                 "against the HBM peak but not fed from HBM" if 4464 * B < 200e6 else "more than the 256 MiB Infinity Cache holds: fed from HBM")) if not kin_mode
-                               else "device-resident robot state only (joint state, MPC chain records, reference window): no Jacobian bytes cross HBM"},
+                               else ("device-resident robot state only (joint state, MPC chain records, reference window): no Jacobian bytes cross HBM" if args.tick_kin_handoff == "fused"
+                                     else "device-resident robot state + the kinematics launch's Jacobian hand-off, written and read back every tick (%s)" % args.tick_kin_handoff)},
         "solved": {"ticks_executed": out_state["tick"], "mpc_fail": int(out_state["mpc_fail"].sum()),
                    "ik_fail": int(out_state["ik_fail"].sum()), "robots_with_ik_fail": int((out_state["ik_fail"] > 0).sum()), "of": B * T,
                    "stopped_robot_ticks_not_counted": stopped_ticks_all,
