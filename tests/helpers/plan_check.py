@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import walking_controllers_amd as wca
 
 
-def main(B, ways, R=7, horizon=50):
+def main(B, ways, R=7, horizon=50, graph=False):
     dev = torch.device("cuda", 0)
     mpc, ik = wca.MpcSolver(horizon=horizon), wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, jacobian_structure=wca.IK_JAC_MIXED)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -53,6 +53,23 @@ def main(B, ways, R=7, horizon=50):
         for k in a:
             assert torch.equal(a[k], b[k]), (B, ways, n, k)
     assert (got_o[0]["ms"] == 0).all() and sum(int((o["ma"] != 0).sum()) for o in got_o) > 0          # hull rows really bind somewhere
+    if graph:
+        # wcqp_qp_plan_enqueue is "enqueue only; graph-capturable" (include/wcqp.h): captured into a hipGraph and replayed twice,
+        # the outputs cleared in between (the work-queue form re-arms its ticket counters inside the launch itself)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+            plan.enqueue(st.cuda_stream)
+        for _ in range(2):
+            for o in got_o:
+                for v in o.values():
+                    v.zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for n, (a, b) in enumerate(zip(ref_o, got_o)):
+                for k in a:
+                    assert torch.equal(a[k], b[k]), ("graph", B, ways, n, k)
+        del g
     plan.close()
     # a plan needs what one launch can do: an IK handle with the general fall-back behind it is refused
     try:
@@ -67,6 +84,8 @@ if __name__ == "__main__":
         # (4096 robots x 7 records = 7168 units for the 2048 wavefronts that are resident at once; the replay starts from the queue the first launch put back)
         main(B, ways)
     main(8192, 0, R=5)
+    main(777, 3, graph=True)
+    main(4096, 0, graph=True)
     main(333, 0, R=3, horizon=200)
     main(333, 2, R=3, horizon=200)                                         # the shipped horizon: more than one 64-stage pass of the window
     main(64, 1, R=2, horizon=7)
