@@ -4,7 +4,7 @@
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../walking-controllers_amd/csrc"
-make -s >/dev/null
+make -s >/dev/null      # NOTE: rebuilds the PRODUCT library from the working tree as well - A/B a source change against a variant built from a stash, not against "the product"
 mkdir -p build/diag
 for f in ik ik2 ik3 ik4 kin tick; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -DWCQP_DIAG_KERNELS "$@" -x hip -c $f.hip -o build/diag/${f}_$name.o
