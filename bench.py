@@ -449,6 +449,72 @@ def main():
     ik_ms_res = kernel_ms(lambda d: launch_ik(d, ik_one), pipes[0][0], False)
     mpc_ms = kernel_ms(lambda d: launch_mpc(d, sp), stream, True)
     mpc_ms_res = kernel_ms(lambda d: launch_mpc(d, sp), stream, False)
+    # BASELINE config 2 on its own (batched DCM-MPC): the MPC-only plan - one launch walks through the batches, 16-17 wavefronts per
+    # robot group - over MPC input sets of its own (> 1 GiB of them: the K sets above hold far less MPC data than the Infinity Cache)
+    mpc_plan_ms = None
+    if not exch:
+        try:
+            m_bytes = B * (mpc_bytes - 16)
+            KM = int(max(13, min(512, -(-(1 << 30) // m_bytes))))
+            wm = 16
+            while math.gcd(KM, wm) != 1:
+                wm += 1
+            mkeys = ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc")
+            msets = [{k: base[k] for k in mkeys}] + [{k: torch.roll(base[k], shifts=j * max(1, B // KM), dims=0).contiguous() for k in mkeys} for j in range(1, KM)]
+            mouts = [dict(u0=torch.zeros(B, 2, dtype=torch.float64, device=dev), mstat=torch.zeros(B, dtype=torch.int32, device=dev),
+                          mact=torch.zeros(B, dtype=torch.int32, device=dev), mmar=torch.zeros(B, dtype=torch.float64, device=dev)) for _ in range(wm)]
+            nm = max(args.steps, 200)
+            mrecs = (wca.capi.QpStep * nm)()
+            for t_ in range(nm):
+                d_, o_, r = msets[t_ % KM], mouts[t_ % wm], mrecs[t_]
+                r.x0, r.ref, r.ref_len, r.u_prev, r.hull_A, r.hull_b, r.hull_nc = (d_["x0"].data_ptr(), d_["ref"].data_ptr(), N1, d_["u_prev"].data_ptr(),
+                                                                                     d_["hull_A"].data_ptr(), d_["hull_b"].data_ptr(), d_["hull_nc"].data_ptr())
+                r.u0, r.mpc_status, r.mpc_active, r.mpc_margin = o_["u0"].data_ptr(), o_["mstat"].data_ptr(), o_["mact"].data_ptr(), o_["mmar"].data_ptr()
+            mpl = wca.capi.QpPlan(mpc, None, B, mrecs, ways=wm)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            mpl.enqueue(sp); mpl.enqueue(sp)
+            torch.cuda.synchronize(dev)
+            e0.record(stream)
+            for _ in range(5):
+                mpl.enqueue(sp)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            mpc_plan_ms = e0.elapsed_time(e1) / 5 / nm
+            mpc_plan_ok = min(int(((o_["mstat"] == 0) | (o_["mstat"] == 3)).sum().item()) for o_ in mouts)
+            mpl.close()
+            del msets, mouts
+        except Exception as e:
+            print("bench.py: MPC-only plan pass skipped (%r)" % (e,), file=sys.stderr)
+    # BASELINE config 3 on its own (batched QP-IK): the IK-only plan - qp_plan_kernel without its MPC share - over the K cold input sets
+    ik_plan_ms = None
+    if not exch and args.ik_jac == "mixed":
+        try:
+            wi = 5
+            while math.gcd(K, wi) != 1:
+                wi += 1
+            iouts = [outputs() for _ in range(wi)]
+            ni = max(args.steps, 100)
+            irecs = (wca.capi.QpStep * ni)()
+            for t_ in range(ni):
+                q_, o_, r = sets[t_ % K]["_ik"], iouts[t_ % wi], irecs[t_]
+                r.J_left, r.J_right, r.J_neck, r.J_com, r.q, r.state = q_
+                r.dq, r.ik_status, r.active_lower, r.active_upper, r.foot_err, r.iters = (o_["dq"].data_ptr(), o_["istat"].data_ptr(), o_["ilo"].data_ptr(),
+                                                                                           o_["iup"].data_ptr(), None, o_["iit"].data_ptr())
+            ipl = wca.capi.QpPlan(None, ik, B, irecs, ways=wi)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ipl.enqueue(sp); ipl.enqueue(sp)
+            torch.cuda.synchronize(dev)
+            e0.record(stream)
+            for _ in range(5):
+                ipl.enqueue(sp)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ik_plan_ms = e0.elapsed_time(e1) / 5 / ni
+            ik_plan_ok = min(int((o_["istat"] == 0).sum().item()) for o_ in iouts)
+            ipl.close()
+            del iouts
+        except Exception as e:
+            print("bench.py: IK-only plan pass skipped (%r)" % (e,), file=sys.stderr)
     ik_auto = wca.IkSolver(form=ik_form, v_max=args.ik_vmax, jacobian_structure=wca.IK_JAC_AUTO)
     ik_auto_ms = kernel_ms(lambda d: launch_ik(d, ik_auto), pipes[0][0], True)
 
@@ -569,6 +635,14 @@ def main():
             "ik_auto_ms": ik_auto_ms, "ik_auto_fallback_launch_ms": ik_auto_ms - ik_ms,
             "mpc_ms": mpc_ms, "mpc_ms_resident_inputs": mpc_ms_res, "mpc_qps_per_gpu": B / (mpc_ms * 1e-3),
             "mpc_hbm_frac": mpc_bytes * B / (mpc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "mpc_bytes_per_qp": mpc_bytes,
+            # BASELINE config 2 alone, as ONE launch over many batches (wcqp_qp_plan_* with MPC-only records, mpc_plan_kernel)
+            "mpc_plan_ms_per_batch": mpc_plan_ms, "mpc_plan_qps_per_gpu": (B / (mpc_plan_ms * 1e-3)) if mpc_plan_ms else None,
+            "mpc_plan_hbm_frac": (mpc_bytes * B / (mpc_plan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mpc_plan_ms else None,
+            "mpc_plan_solved": (mpc_plan_ok if mpc_plan_ms else None),
+            # BASELINE config 3 alone, as ONE launch over many batches (wcqp_qp_plan_* with IK-only records: qp_plan_kernel without its MPC share)
+            "ik_plan_ms_per_batch": ik_plan_ms, "ik_plan_qps_per_gpu": (B / (ik_plan_ms * 1e-3)) if ik_plan_ms else None,
+            "ik_plan_hbm_frac": (IK_BYTES_PER_QP * B / (ik_plan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ik_plan_ms else None,
+            "ik_plan_solved": (ik_plan_ok if ik_plan_ms else None),
         },
         "solved": dict({"ik": n_ok_ik, "mpc": n_ok_mpc, "of": B, "ik_mean_active_set_changes": ik_iters,
                         "ik_frac_with_active_bounds": frac_active}, **golden),

@@ -298,7 +298,10 @@ int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch,
  * next (record, robot group) unit - robot-group-major - from a device-side queue when it is done with one, so that no wave slot
  * idles while another wavefront still has records left (the tail of the fixed ways).  Any two records may then be in flight
  * together and in any order: NO two records of the plan may share an output array.  The queue is re-armed by the launch itself;
- * launches of ONE plan must be ordered (one stream at a time), different plans are independent.  Every
+ * launches of ONE plan must be ordered (one stream at a time), different plans are independent.
+ * A plan in which NO record has an IK part (J_left == NULL in every record; `ik` may then be NULL, ways >= 1) is an MPC-only plan -
+ * BASELINE config 2 on its own: one launch walks through the DCM-MPC batches; one in which NO record has an MPC part (x0 == NULL in
+ * every record) is an IK-only plan - config 3 on its own.  Otherwise every
  * record needs both parts; the stream fields of the records are ignored (wcqp_qp_plan_enqueue names the stream).
  * WCQP_E_UNSUPPORTED unless the IK handle runs its default kernel with jacobian_structure = WCQP_IK_JAC_MIXED: use
  * wcqp_qp_enqueue_steps then.  Same results as the single calls, bit for bit.  The arrays the

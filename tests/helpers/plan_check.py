@@ -71,6 +71,39 @@ def main(B, ways, R=7, horizon=50, graph=False):
                     assert torch.equal(a[k], b[k]), ("graph", B, ways, n, k)
         del g
     plan.close()
+    # MPC-only plan (no record has an IK part; the IK handle may be missing): bit for bit the single MPC calls
+    mrecs = (wca.capi.QpStep * R)()
+    mo = [outs() for _ in range(R)]
+    for n, ((m, i), o) in enumerate(zip(sets, mo)):
+        r = mrecs[n]
+        r.x0, r.ref, r.ref_len, r.u_prev = m["x0"].data_ptr(), m["ref"].data_ptr(), N1, m["u_prev"].data_ptr()
+        r.hull_A, r.hull_b, r.hull_nc = m["hull_A"].data_ptr(), m["hull_b"].data_ptr(), m["hull_nc"].data_ptr()
+        r.u0, r.mpc_status, r.mpc_active, r.mpc_margin = o["u0"].data_ptr(), o["ms"].data_ptr(), o["ma"].data_ptr(), o["mm"].data_ptr()
+    mplan = wca.capi.QpPlan(mpc, None, B, mrecs, ways=max(1, ways))
+    mplan.enqueue(st.cuda_stream); mplan.enqueue(st.cuda_stream)
+    torch.cuda.synchronize()
+    for n, (a, b) in enumerate(zip(ref_o, mo)):
+        for k in ("u0", "ms", "ma", "mm"):
+            assert torch.equal(a[k], b[k]), ("mpc-only", B, ways, n, k)
+        assert (b["st"] == -1).all() and (b["dq"] == 0).all()          # the IK outputs were not touched
+    mplan.close()
+    # IK-only plan (no record has an MPC part; the MPC handle may be missing): bit for bit the single IK calls
+    irecs = (wca.capi.QpStep * R)()
+    io = [outs() for _ in range(R)]
+    for n, ((m, i), o) in enumerate(zip(sets, io)):
+        r = irecs[n]
+        r.J_left, r.J_right, r.J_neck, r.J_com = (i[k].data_ptr() for k in ("J_left", "J_right", "J_neck", "J_com"))
+        r.q, r.state = i["q"].data_ptr(), i["state"].data_ptr()
+        r.dq, r.ik_status, r.active_lower, r.active_upper = o["dq"].data_ptr(), o["st"].data_ptr(), o["lo"].data_ptr(), o["up"].data_ptr()
+        r.foot_err, r.iters = o["fe"].data_ptr(), o["it"].data_ptr()
+    iplan = wca.capi.QpPlan(None, ik, B, irecs, ways=ways)
+    iplan.enqueue(st.cuda_stream); iplan.enqueue(st.cuda_stream)
+    torch.cuda.synchronize()
+    for n, (a, b) in enumerate(zip(ref_o, io)):
+        for k in ("dq", "st", "lo", "up", "fe", "it"):
+            assert torch.equal(a[k], b[k]), ("ik-only", B, ways, n, k)
+        assert (b["ms"] == -1).all() and (b["u0"] == 0).all()          # the MPC outputs were not touched
+    iplan.close()
     # a plan needs what one launch can do: an IK handle with the general fall-back behind it is refused
     try:
         wca.capi.QpPlan(mpc, wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.4, jacobian_structure=wca.IK_JAC_AUTO), B, recs)

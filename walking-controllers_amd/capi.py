@@ -87,12 +87,14 @@ def qp_enqueue_steps(mpc, ik, batch, steps):
 class QpPlan:
     """wcqp_qp_plan_*: the records of qp_enqueue_steps uploaded once, replayed as ONE launch that walks through them; `ways`
     wavefronts share a robot group (way w takes records w, w + ways, ...: records of different ways need their own outputs);
-    ways = 0: a work queue over (record, robot group) units - every record needs outputs of its own."""
+    ways = 0: a work queue over (record, robot group) units - every record needs outputs of its own.
+    Records without an IK part (J_left = None in all of them; ik may be None): an MPC-only plan; without an MPC part (x0 = None; mpc may
+    be None): an IK-only plan."""
 
     def __init__(self, mpc, ik, batch, steps, ways=1):
         self._h = C.c_void_p()
         self._keep = (mpc, ik, steps)
-        check(lib().wcqp_qp_plan_create(mpc._h, ik._h, int(batch), len(steps), steps, int(ways), C.byref(self._h)), "wcqp_qp_plan_create")
+        check(lib().wcqp_qp_plan_create(mpc._h if mpc is not None else None, ik._h if ik is not None else None, int(batch), len(steps), steps, int(ways), C.byref(self._h)), "wcqp_qp_plan_create")
 
     def enqueue(self, stream=0):
         check(lib().wcqp_qp_plan_enqueue(self._h, stream or None), "wcqp_qp_plan_enqueue")

@@ -611,24 +611,48 @@ struct wcqp_qp_plan_s {
     wcqp_qp_step* d_recs = nullptr;
     unsigned* d_queue = nullptr;      // ways = 0: ticket counters + waves done (ik_common.h: kPlanQueues; qp_plan_kernel zeroes them itself)
     int queue_grid = 0;
+    bool mpc_only = false;            // every record without its IK part: mpc_plan_kernel (mpc.hip)
 };
 
 extern "C" {
 
 int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_steps, const wcqp_qp_step* steps, int32_t ways,
                         wcqp_qp_plan_t* out) {
-    if (!mpc || !ik || !out || batch < 1 || n_steps < 1 || !steps || ways < 0) return WCQP_E_INVALID;
+    if (!out || batch < 1 || n_steps < 1 || !steps || ways < 0) return WCQP_E_INVALID;
+    // MPC-only plan: NO record has an IK part (J_left == NULL everywhere; `ik` may be NULL): BASELINE config 2 on its own
+    bool mpc_only = true;
+    for (int k = 0; k < n_steps; ++k) mpc_only = mpc_only && !steps[k].J_left;
+    // IK-only plan: NO record has an MPC part (x0 == NULL everywhere): BASELINE config 3 on its own (qp_plan_kernel without its MPC share)
+    bool ik_only = true;
+    for (int k = 0; k < n_steps; ++k) ik_only = ik_only && !steps[k].x0;
+    if (mpc_only && ik_only) return WCQP_E_INVALID;
+    if (!mpc && !ik_only) return WCQP_E_INVALID;         // (`mpc` may be NULL for an IK-only plan, `ik` for an MPC-only one)
+    for (int k = 0; k < n_steps; ++k) {
+        const wcqp_qp_step& s = steps[k];
+        if (!ik_only && (!s.x0 || !s.ref || s.ref_len < 1 || !s.u_prev || !s.hull_A || !s.hull_b || !s.hull_nc || !s.u0 || !s.mpc_status)) return WCQP_E_INVALID;
+        if (!mpc_only && (!s.J_left || !s.J_right || !s.J_neck || !s.J_com || !s.q || !s.state || !s.dq || !s.ik_status)) return WCQP_E_INVALID;
+    }
+    if (mpc_only) {
+        if (ways < 1) return WCQP_E_UNSUPPORTED;        // the work-queue form belongs to the IK + MPC kernel
+        int rc0 = wcqp::mpc_prepare(mpc);
+        if (rc0 != WCQP_OK) return rc0;
+        wcqp_qp_plan_s* p = new (std::nothrow) wcqp_qp_plan_s();
+        if (!p) return WCQP_E_NOMEM;
+        p->mpc = mpc; p->batch = batch; p->n_steps = n_steps; p->ways = ways < n_steps ? ways : n_steps; p->mpc_only = true;
+        if (hipMalloc(reinterpret_cast<void**>(&p->d_recs), (size_t)n_steps * sizeof(wcqp_qp_step)) != hipSuccess) { delete p; return WCQP_E_NOMEM; }
+        if (hipMemcpy(p->d_recs, steps, (size_t)n_steps * sizeof(wcqp_qp_step), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(p->d_recs); delete p; return WCQP_E_HIP;
+        }
+        *out = p;
+        return WCQP_OK;
+    }
+    if (!ik) return WCQP_E_INVALID;
     // one launch walks through the records: that is the base-eliminated kernel on Jacobians the caller declares MIXED (no
     // fall-back launch behind it), with the MPC on the IK's lanes
     const bool want4 = ik->p.algorithm == WCQP_IK_ALG_BASE_ELIM || ik->p.algorithm == WCQP_IK_ALG_DEFAULT;
     if (!(want4 && ik->hp.fast_ok && ik->p.jacobian_structure == WCQP_IK_JAC_MIXED)) return WCQP_E_UNSUPPORTED;
-    for (int k = 0; k < n_steps; ++k) {
-        const wcqp_qp_step& s = steps[k];
-        if (!s.x0 || !s.ref || s.ref_len < 1 || !s.u_prev || !s.hull_A || !s.hull_b || !s.hull_nc || !s.u0 || !s.mpc_status) return WCQP_E_INVALID;
-        if (!s.J_left || !s.J_right || !s.J_neck || !s.J_com || !s.q || !s.state || !s.dq || !s.ik_status) return WCQP_E_INVALID;
-    }
     int rc = ensure_device(ik);
-    if (rc == WCQP_OK) rc = wcqp::mpc_prepare(mpc);
+    if (rc == WCQP_OK && mpc) rc = wcqp::mpc_prepare(mpc);
     if (rc != WCQP_OK) return rc;
     wcqp_qp_plan_s* p = new (std::nothrow) wcqp_qp_plan_s();
     if (!p) return WCQP_E_NOMEM;
@@ -651,8 +675,9 @@ int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_s
 
 int wcqp_qp_plan_enqueue(wcqp_qp_plan_t p, void* stream) {
     if (!p) return WCQP_E_INVALID;
-    wcqp_mpc::MpcDeviceConsts c;
-    wcqp::mpc_device_consts(p->mpc, &c);
+    if (p->mpc_only) return wcqp::mpc_launch_plan(p->mpc, p->batch, p->d_recs, p->n_steps, p->ways, (hipStream_t)stream);
+    wcqp_mpc::MpcDeviceConsts c{};
+    if (p->mpc) wcqp::mpc_device_consts(p->mpc, &c);        // (an IK-only plan never reads them)
     return wcqp_ik::ik4_launch_plan(p->ik->d_prm, p->batch, p->d_recs, p->n_steps, p->ways, c, (hipStream_t)stream, p->d_queue, p->queue_grid);
 }
 

@@ -198,12 +198,14 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     wcqp_tick::TickMpcRegs mreg;
     double2 p_xs = make_double2(0.0, 0.0), p_up = make_double2(0.0, 0.0);
     if constexpr (PAIR) {
+        if (pm->x0) {          // (an IK-only plan has no MPC part: wave-uniform)
         const double2* rp = reinterpret_cast<const double2*>(pm->ref) + inst * pm->ref_len;
         wcqp_mpc::mpc_window_loads(pm->c, j, rp, pm->ref_len, mreg.L);
         if (j == 0) { p_xs = reinterpret_cast<const double2*>(pm->x0)[inst]; p_up = reinterpret_cast<const double2*>(pm->u_prev)[inst]; }
         mreg.nc = pm->hull_nc[inst];
         mreg.ha = make_double2(0.0, 0.0); mreg.hb = 0.0;
         if (j < WCQP_HULL_ROWS) { mreg.ha = reinterpret_cast<const double2*>(pm->hull_A)[inst * WCQP_HULL_ROWS + j]; mreg.hb = pm->hull_b[inst * WCQP_HULL_ROWS + j]; }
+        }
     }
     if constexpr (TICK) { if (do_mpc) wcqp_tick::tick_mpc_issue<KINF>(td, j, inst, tick_now + 1, mreg); else mreg.phase0 = td.phase0[inst]; }
     double2 cr0[5], cr1[5], cdv[5];        // COMPACT: the two joint records and the three vectors p_frame - p_base, as loaded
@@ -551,7 +553,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             if (pm->ticket_from && threadIdx.x == 0) pm->ticket = __hip_atomic_fetch_add(pm->ticket_from, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (PAIR) {
+        if constexpr (PAIR) if (pm->x0) {
             // the DCM-MPC QP of the same four robots while the Jacobians are on their way: the operations of mpc_row_solve, in its order
             double ux, uy, u0x, u0y, margin;
             int mst_;
@@ -1678,7 +1680,7 @@ void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcq
         // (the record's pointers come out of memory: as_global says what a kernel argument would have said - gptr.h)
         using wcqp::as_global;
         const wcqp_qp_step& s = recs[r];
-        MpcPairArgs m{c, as_global(s.x0), as_global(s.ref), s.ref_len, as_global(s.u_prev), as_global(s.hull_A), as_global(s.hull_b), as_global(s.hull_nc),
+        MpcPairArgs m{c, s.x0 ? as_global(s.x0) : nullptr, as_global(s.ref), s.ref_len, as_global(s.u_prev), as_global(s.hull_A), as_global(s.hull_b), as_global(s.hull_nc),
                       as_global(s.u0), as_global(s.mpc_status), as_global(s.mpc_active), as_global(s.mpc_margin),
                       dynamic ? queue + home * QS + z : nullptr, 0u};
         ik4_body<false, 0, true>(prm, batch, as_global(s.J_left), as_global(s.J_right), as_global(s.J_neck), as_global(s.J_com), as_global(s.q), as_global(s.state),

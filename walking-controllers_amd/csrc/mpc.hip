@@ -65,6 +65,42 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
     }
 }
 
+// A plan of MPC-only records (include/wcqp.h: wcqp_qp_plan_*; the IK + MPC plans live in ik4.hip): workgroup (way, robot group)
+// solves robots 4g .. 4g+3 of records way, way + ways, ... - BASELINE config 2 (batched DCM-MPC, B = 4096) is 4.3 MB per batch, a
+// launch of its own is all ramp-up (5.7 us = 0.12 of the roofline); walked through in one launch, with the kernel's 65 registers
+// allowing seven waves per SIMD, the card has many batches' loads in flight.  The record's pointers come out of memory: as_global.
+__global__ __launch_bounds__(kBlock)
+void mpc_plan_kernel(MpcDeviceConsts c, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups)
+{
+    __shared__ __attribute__((aligned(16))) double s_hull[kInstPerWave][WCQP_HULL_ROWS][4];
+    using wcqp::as_global;
+    const int way = (int)blockIdx.x / groups, blk = (int)blockIdx.x % groups;
+#pragma unroll 1
+    for (int r = way; r < n_steps; r += ways) {
+        __asm__ volatile("" ::: "memory");
+        int lane = threadIdx.x;
+        __asm__ volatile("" : "+v"(lane));          // per-lane addresses are recomputed per record, not hoisted (they would all stay live)
+        const int sub = lane / kLanesPerInstance, t = lane % kLanesPerInstance;
+        const long inst_raw = (long)blk * kInstPerWave + sub;
+        const bool live = inst_raw < batch;
+        const long inst = live ? inst_raw : (long)batch - 1;
+        const wcqp_qp_step& s = recs[r];
+        const double2* rp = reinterpret_cast<const double2*>(as_global(s.ref)) + inst * s.ref_len;
+        double ux, uy, margin;
+        int st;
+        unsigned mask;
+        mpc_row_solve(c, t, inst, as_global(s.x0), rp, s.ref_len, as_global(s.u_prev), as_global(s.hull_A), as_global(s.hull_b), as_global(s.hull_nc), inst,
+                      s_hull[sub], ux, uy, st, mask, margin);
+        if (t == 0 && live) {
+            reinterpret_cast<double2*>(as_global(s.u0))[inst] = make_double2(ux, uy);
+            as_global(s.mpc_status)[inst] = st;
+            if (s.mpc_active) as_global(s.mpc_active)[inst] = mask;
+            if (s.mpc_margin) as_global(s.mpc_margin)[inst] = margin;
+        }
+        wcqp::wave_lds_fence();      // s_hull is rewritten by the next record
+    }
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -209,6 +245,15 @@ int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, in
 }
 
 int mpc_prepare(wcqp_mpc_t h) { return h ? ensure_device(h) : WCQP_E_INVALID; }
+int mpc_launch_plan(wcqp_mpc_t h, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways, hipStream_t stream) {
+    if (!h || !d_recs || batch < 1 || n_steps < 1 || ways < 1) return WCQP_E_INVALID;
+    wcqp_mpc::MpcDeviceConsts c;
+    mpc_device_consts(h, &c);
+    const int groups = (batch + wcqp_mpc::kInstPerWave - 1) / wcqp_mpc::kInstPerWave;
+    hipLaunchKernelGGL(mpc_plan_kernel, dim3((unsigned)(groups * ways)), dim3(kBlock), 0, stream, c, batch, d_recs, n_steps, ways, groups);
+    WCQP_HIP_TRY(hipGetLastError());
+    return WCQP_OK;
+}
 void mpc_device_consts(wcqp_mpc_t h, wcqp_mpc::MpcDeviceConsts* c) {
     c->Gr = h->d_Gr;
     std::memcpy(c->Gx, h->Gx, sizeof(c->Gx));

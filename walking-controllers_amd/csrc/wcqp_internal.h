@@ -39,6 +39,7 @@ int mpc_enqueue(wcqp_mpc_t h, int batch, const double* x0, const double* ref, in
                 double* u0, int* status, unsigned* active, double* margin, hipStream_t stream);
 int mpc_horizon(wcqp_mpc_t h);
 int mpc_prepare(wcqp_mpc_t h);     // uploads the handle's device constants now (graph capture forbids it later)
+int mpc_launch_plan(wcqp_mpc_t h, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways, hipStream_t stream);   // MPC-only plan (mpc.hip)
 int ik_prepare(wcqp_ik_t h);
 const void* ik_device_params(wcqp_ik_t h);     // IkDeviceParams* in HBM (after ik_prepare)
 int qp_pair_enqueue(wcqp_mpc_t mpc, wcqp_ik_t ik, int batch, const wcqp_qp_step& s);   // WCQP_E_UNSUPPORTED: make the two calls instead
