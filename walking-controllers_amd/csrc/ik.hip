@@ -612,6 +612,7 @@ struct wcqp_qp_plan_s {
     unsigned* d_queue = nullptr;      // ways = 0: ticket counters + waves done (ik_common.h: kPlanQueues; qp_plan_kernel zeroes them itself)
     int queue_grid = 0;
     bool mpc_only = false;            // every record without its IK part: mpc_plan_kernel (mpc.hip)
+    bool ik_only = false;             // every record without its MPC part: ik_plan_kernel (ik4.hip)
 };
 
 extern "C" {
@@ -656,7 +657,7 @@ int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_s
     if (rc != WCQP_OK) return rc;
     wcqp_qp_plan_s* p = new (std::nothrow) wcqp_qp_plan_s();
     if (!p) return WCQP_E_NOMEM;
-    p->mpc = mpc; p->ik = ik; p->batch = batch; p->n_steps = n_steps; p->ways = ways < n_steps ? ways : n_steps;
+    p->mpc = mpc; p->ik = ik; p->batch = batch; p->n_steps = n_steps; p->ways = ways < n_steps ? ways : n_steps; p->ik_only = ik_only;
     if (hipMalloc(reinterpret_cast<void**>(&p->d_recs), (size_t)n_steps * sizeof(wcqp_qp_step)) != hipSuccess) { delete p; return WCQP_E_NOMEM; }
     if (hipMemcpy(p->d_recs, steps, (size_t)n_steps * sizeof(wcqp_qp_step), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(p->d_recs); delete p; return WCQP_E_HIP;
@@ -678,7 +679,7 @@ int wcqp_qp_plan_enqueue(wcqp_qp_plan_t p, void* stream) {
     if (p->mpc_only) return wcqp::mpc_launch_plan(p->mpc, p->batch, p->d_recs, p->n_steps, p->ways, (hipStream_t)stream);
     wcqp_mpc::MpcDeviceConsts c{};
     if (p->mpc) wcqp::mpc_device_consts(p->mpc, &c);        // (an IK-only plan never reads them)
-    return wcqp_ik::ik4_launch_plan(p->ik->d_prm, p->batch, p->d_recs, p->n_steps, p->ways, c, (hipStream_t)stream, p->d_queue, p->queue_grid);
+    return wcqp_ik::ik4_launch_plan(p->ik->d_prm, p->batch, p->d_recs, p->n_steps, p->ways, c, (hipStream_t)stream, p->d_queue, p->queue_grid, p->ik_only);
 }
 
 int wcqp_qp_plan_destroy(wcqp_qp_plan_t p) {

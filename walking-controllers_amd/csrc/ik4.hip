@@ -125,6 +125,7 @@ struct MpcPairArgs {
     // vmcnt retires in order, and a device-scope atomic issued in front of them would hold every load of the record back by its
     // own, longer, round trip - and leaves it here for the bottom of the loop
     unsigned* ticket_from = nullptr; unsigned ticket = 0;
+    bool has_mpc = true;       // false: ik_plan_kernel (an IK-only plan): the record has no MPC part
 };
 
 // PAIR (a plan of steps, wcqp_qp_plan_*): the wave also solves the DCM-MPC QP of its four robots, its loads issued in front
@@ -198,7 +199,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     wcqp_tick::TickMpcRegs mreg;
     double2 p_xs = make_double2(0.0, 0.0), p_up = make_double2(0.0, 0.0);
     if constexpr (PAIR) {
-        if (pm->x0) {          // (an IK-only plan has no MPC part: wave-uniform)
+        if (pm->has_mpc) {          // (an IK-only plan has no MPC part: a compile-time constant in either plan kernel)
         const double2* rp = reinterpret_cast<const double2*>(pm->ref) + inst * pm->ref_len;
         wcqp_mpc::mpc_window_loads(pm->c, j, rp, pm->ref_len, mreg.L);
         if (j == 0) { p_xs = reinterpret_cast<const double2*>(pm->x0)[inst]; p_up = reinterpret_cast<const double2*>(pm->u_prev)[inst]; }
@@ -553,7 +554,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             if (pm->ticket_from && threadIdx.x == 0) pm->ticket = __hip_atomic_fetch_add(pm->ticket_from, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (PAIR) if (pm->x0) {
+        if constexpr (PAIR) if (pm->has_mpc) {
             // the DCM-MPC QP of the same four robots while the Jacobians are on their way: the operations of mpc_row_solve, in its order
             double ux, uy, u0x, u0y, margin;
             int mst_;
@@ -1636,11 +1637,11 @@ void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 // batches, so nothing orders them: workgroup (way w, robot group g) solves robots 4g .. 4g+3 of records w, w + ways, ... on
 // its own - no launch, ramp-up or tail per step, the MPC of a record in the shadow of its IK's Jacobian loads, and with
 // `ways` workgroups per robot group the BASELINE batch (1024 robot groups) fills both wave slots of every SIMD.
-__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
-void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups,
-                    wcqp_mpc::MpcDeviceConsts c, unsigned* queue)
+template <bool WITH_MPC>
+__device__ __forceinline__
+void plan_walk(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups,
+               const wcqp_mpc::MpcDeviceConsts& c, unsigned* queue, double (*smem)[PER_INST])
 {
-    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
     // ways > 0: workgroup (way, robot group) walks through records way, way + ways, ... of its group.
     // ways = 0, work queues: unit u = (robot group u / n_steps, record u % n_steps), GROUP-major: the resident waves then work inside a
     // window of a few dozen robot groups (record-major at 65536 robots every unit of a wave lies 11 MB further on in each of the
@@ -1680,9 +1681,11 @@ void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcq
         // (the record's pointers come out of memory: as_global says what a kernel argument would have said - gptr.h)
         using wcqp::as_global;
         const wcqp_qp_step& s = recs[r];
-        MpcPairArgs m{c, s.x0 ? as_global(s.x0) : nullptr, as_global(s.ref), s.ref_len, as_global(s.u_prev), as_global(s.hull_A), as_global(s.hull_b), as_global(s.hull_nc),
-                      as_global(s.u0), as_global(s.mpc_status), as_global(s.mpc_active), as_global(s.mpc_margin),
-                      dynamic ? queue + home * QS + z : nullptr, 0u};
+        MpcPairArgs m{c, WITH_MPC ? as_global(s.x0) : nullptr, WITH_MPC ? as_global(s.ref) : nullptr, s.ref_len, WITH_MPC ? as_global(s.u_prev) : nullptr,
+                      WITH_MPC ? as_global(s.hull_A) : nullptr, WITH_MPC ? as_global(s.hull_b) : nullptr, WITH_MPC ? as_global(s.hull_nc) : nullptr,
+                      WITH_MPC ? as_global(s.u0) : nullptr, WITH_MPC ? as_global(s.mpc_status) : nullptr, WITH_MPC ? as_global(s.mpc_active) : nullptr,
+                      WITH_MPC ? as_global(s.mpc_margin) : nullptr,
+                      dynamic ? queue + home * QS + z : nullptr, 0u, WITH_MPC};
         ik4_body<false, 0, true>(prm, batch, as_global(s.J_left), as_global(s.J_right), as_global(s.J_neck), as_global(s.J_com), as_global(s.q), as_global(s.state),
                                  as_global(s.dq), as_global(s.ik_status), as_global(s.active_lower), as_global(s.active_upper),
                                  as_global(s.foot_err), as_global(s.iters), wcqp_tick::TickDev{}, smem, blk, 0, true, nullptr, nullptr, &m);
@@ -1703,6 +1706,23 @@ void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcq
     }
 }
 
+__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
+void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups,
+                    wcqp_mpc::MpcDeviceConsts c, unsigned* queue)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
+    plan_walk<true>(prm, batch, recs, n_steps, ways, groups, c, queue, smem);
+}
+// an IK-only plan (no record has an MPC part: BASELINE config 3 on its own): the same walk without the MPC share, under a name of its
+// own so that profiles of the two do not mix
+__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
+void ik_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups,
+                    wcqp_mpc::MpcDeviceConsts c, unsigned* queue)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4][PER_INST];
+    plan_walk<false>(prm, batch, recs, n_steps, ways, groups, c, queue, smem);
+}
+
 }  // namespace
 
 namespace wcqp_ik {
@@ -1715,12 +1735,13 @@ int ik4_plan_queue_grid(int batch, int n_steps) {
 }
 
 int ik4_launch_plan(const IkDeviceParams* d_prm, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways,
-                    const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream, unsigned* d_queue, int queue_grid) {
+                    const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream, unsigned* d_queue, int queue_grid, bool ik_only) {
     if (!d_prm || !d_recs || batch < 1 || n_steps < 1 || ways < 0 || (ways == 0 && (!d_queue || queue_grid < 1))) return WCQP_E_INVALID;
     const int groups = (batch + 3) / 4;
     if ((long long)groups * n_steps >= (1ll << 31)) return WCQP_E_INVALID;
     const unsigned grid = ways == 0 ? (unsigned)queue_grid : (unsigned)(groups * ways);
-    hipLaunchKernelGGL(qp_plan_kernel, dim3(grid), dim3(64), 0, stream, d_prm, batch, d_recs, n_steps, ways, groups, c, d_queue);
+    if (ik_only) hipLaunchKernelGGL(ik_plan_kernel, dim3(grid), dim3(64), 0, stream, d_prm, batch, d_recs, n_steps, ways, groups, c, d_queue);
+    else hipLaunchKernelGGL(qp_plan_kernel, dim3(grid), dim3(64), 0, stream, d_prm, batch, d_recs, n_steps, ways, groups, c, d_queue);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }

@@ -398,7 +398,7 @@ int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_
                     unsigned* alo, unsigned* aup, int n_inner, int skip_last_mpc, hipStream_t stream, double* log_ferr = nullptr);
 // a plan of steps in ONE launch (wcqp_qp_plan_*): d_recs = the records in device memory
 int ik4_launch_plan(const IkDeviceParams* d_prm, int batch, const wcqp_qp_step* d_recs, int n_steps, int ways,
-                    const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream, unsigned* d_queue, int queue_grid);
+                    const wcqp_mpc::MpcDeviceConsts& c, hipStream_t stream, unsigned* d_queue, int queue_grid, bool ik_only);
 int ik4_plan_queue_grid(int batch, int n_steps);      // work-queue form (ways = 0): as many waves as are resident at once
 // its ticket counters: kPlanQueues of them + the count of finished waves, kPlanQueueStride bytes apart, all zero between launches
 constexpr unsigned kPlanQueues = 32, kPlanQueueStride = 4352;
