@@ -90,11 +90,13 @@ def main():
                          "per launch); dense / compact = a kinematics launch per tick handing over four dense Jacobians / per-joint records (A/B; same results)")
     ap.add_argument("--ticks-per-launch", type=int, default=0, help="tick workload without per-tick kinematics: ticks the fused kernel runs per launch (0 = the library's default, 1 = one launch per tick)")
     ap.add_argument("--tick-cold-ik", action="store_true", help="tick workload: no IK hot start (every tick walks the active set from the unconstrained optimum)")
-    ap.add_argument("--plan-ways", type=int, default=4,
+    ap.add_argument("--plan-ways", type=int, default=-1,
                     help="qp workload: the timed steps as ONE launch (wcqp_qp_plan_*): consecutive steps are independent batches, so a wavefront "
                          "owns four robots and walks through the steps on its own, the MPC of a step in the shadow of its IK's Jacobian loads; "
                          "W wavefronts share a robot group (way w takes steps w, w + W, ...; each way has its own output buffers, like a "
-                         "pipeline).  0 = one launch per step on --pipelines streams (round-2 form)")
+                         "pipeline).  0 = one launch per step on --pipelines streams (round-2 form); -1 (default) = as many ways as put >= 16384 "
+                         "workgroups into the launch (8 x the card's resident wavefronts: the hardware's workgroup dispatch then evens out the "
+                         "launch's ends), at least 4, at most one per step: 16 at 4096 robots, 4 from 16384 on")
     ap.add_argument("--plan-queue", type=int, choices=[0, 1], default=0,
                     help="plan mode: 1 = the one launch hands out (step, robot group) units from a work queue instead of fixed ways - as many "
                          "wavefronts as are resident at once, each taking the next unit when it is done with one; every timed step then has "
@@ -172,19 +174,28 @@ def main():
     # records, and in that time the card's resident wavefronts have read that many x 2048 x 25 KB.  With 3 sets of 400 MB (65536
     # robots: 1.2 GB "cold" by the first rule) that is 154 MB - the sets were coming out of the Infinity Cache, and the kernel showed
     # 0.65 of the roofline where it is 0.55 with inputs of its own for every step (profiles/r03_plan_queue_distinct_inputs.txt).
-    # At least 13 sets, their number coprime with the ways.  The work-queue form orders the units robot-group-major - the records of
-    # a robot group follow each other within microseconds - so there EVERY step gets input arrays of its own.
+    # Plan mode therefore gives EVERY step input arrays of its own (below); the launch-per-step form keeps > 1 GiB of sets, at least 13.
     import math
+    if args.plan_ways < 0:
+        args.plan_ways = int(max(1, min(args.steps, max(4, -(-16384 // ((B + 3) // 4))))))
     if args.input_sets > 0:
         K = args.input_sets
     elif args.plan_queue and args.workload == "qp":
         K = args.steps + args.warmup
         if K * set_bytes > 96e9:
             raise SystemExit("bench.py: --plan-queue 1 gives every step input arrays of its own; %d steps x %.0f MB do not fit" % (K, set_bytes / 1e6))
+    elif args.plan_ways > 0 and args.workload == "qp":
+        # plan mode: every step input arrays of its own while they fit 64 GB (a 4-way plan behind 13 coprime sets is cold, but e.g. 50 ways
+        # behind 47 sets are not: way w reads set k as its first record and way w - 3 the same set as its second, 63 us = 260 MB of
+        # the card's reads apart - 1.41e9 QP/s where it is 1.32e9; profiles/r03_plan_ways_20steps.txt); beyond that as many as fit
+        # (and never fewer than the > 1 GiB of the launch-per-step rule: the sets behind the timed ones are what the set-up pass reads
+        # last, so the timed region does not find the tail of the set-up in the Infinity Cache)
+        K = int(min(max(args.steps + args.warmup, 13, -(-(1 << 30) // set_bytes)), max(13, 64e9 // set_bytes)))
+        if K < args.steps + args.warmup:
+            while math.gcd(K, max(1, args.plan_ways)) != 1:
+                K += 1
     else:
         K = int(max(13, min(64, -(-(1 << 30) // set_bytes))))
-        while math.gcd(K, max(1, args.plan_ways)) != 1:
-            K += 1
     sets = [base] + [{k: torch.roll(v, shifts=j * max(1, B // K), dims=0).contiguous() for k, v in base.items()} for j in range(1, K)]
     use_plan = (args.plan_ways > 0 and not (args.exchange and dist is not None) and args.streams in (0, 1) and args.ik_jac == "mixed"
                 and not args.step_graph)
@@ -600,7 +611,9 @@ def main():
             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": plan_ms * n_plan, "steps_per_launch": n_plan, "avg_ms_per_step": plan_ms,
             "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B * n_plan,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total; a wavefront returns to a set after %d of its records)" % (K, set_bytes / 1e6, K * set_bytes / 1e9, K // math.gcd(K, max(1, plan_ways if use_plan else 1))),
+            "inputs": ("cold: %d input sets of %.1f MB (%.2f GB in total), " % (K, set_bytes / 1e6, K * set_bytes / 1e9)) +
+                      ("every step of the run reads input arrays of its own" if K >= args.steps + args.warmup else
+                       "visited round-robin; a wavefront returns to a set after %d of its records" % (K // math.gcd(K, max(1, plan_ways if use_plan else 1)))),
             "frac_resident_inputs": ((IK_BYTES_PER_QP + mpc_bytes) * B / (plan_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS) if plan_ms_res else None, "avg_ms_per_step_resident_inputs": plan_ms_res,
             "timed_region": {"achieved": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9,
                              "frac": (IK_BYTES_PER_QP + mpc_bytes) * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
@@ -609,7 +622,9 @@ def main():
             "achieved": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": pair_ms, "algorithmic_bytes_per_launch": (IK_BYTES_PER_QP + mpc_bytes) * B,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total; a wavefront returns to a set after %d of its records)" % (K, set_bytes / 1e6, K * set_bytes / 1e9, K // math.gcd(K, max(1, plan_ways if use_plan else 1))),
+            "inputs": ("cold: %d input sets of %.1f MB (%.2f GB in total), " % (K, set_bytes / 1e6, K * set_bytes / 1e9)) +
+                      ("every step of the run reads input arrays of its own" if K >= args.steps + args.warmup else
+                       "visited round-robin; a wavefront returns to a set after %d of its records" % (K // math.gcd(K, max(1, plan_ways if use_plan else 1)))),
             "frac_resident_inputs": (IK_BYTES_PER_QP + mpc_bytes) * B / (pair_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": pair_ms_res,
             # `frac` prices ONE launch running alone (back-to-back launches of the kernel on one stream: what `rocprofv3 --stats`
             # reports for a --pipelines 1 run); with P batches in flight the launches overlap, each takes longer, and the
@@ -620,7 +635,9 @@ def main():
             "bound": "hbm", "kernel": ik_kernel,
             "achieved": ik_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ik_gbs / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": ik_ms, "algorithmic_bytes_per_launch": IK_BYTES_PER_QP * B,
-            "inputs": "cold: %d input sets of %.1f MB visited round-robin (%.2f GB in total; a wavefront returns to a set after %d of its records)" % (K, set_bytes / 1e6, K * set_bytes / 1e9, K // math.gcd(K, max(1, plan_ways if use_plan else 1))),
+            "inputs": ("cold: %d input sets of %.1f MB (%.2f GB in total), " % (K, set_bytes / 1e6, K * set_bytes / 1e9)) +
+                      ("every step of the run reads input arrays of its own" if K >= args.steps + args.warmup else
+                       "visited round-robin; a wavefront returns to a set after %d of its records" % (K // math.gcd(K, max(1, plan_ways if use_plan else 1)))),
             "frac_resident_inputs": IK_BYTES_PER_QP * B / (ik_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_resident_inputs": ik_ms_res,
         }),
         "kernels": {

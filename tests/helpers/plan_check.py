@@ -113,12 +113,13 @@ def main(B, ways, R=7, horizon=50, graph=False):
 
 
 if __name__ == "__main__":
-    for B, ways in ((1, 1), (5, 3), (777, 2), (4096, 2), (4096, 9), (1, 0), (777, 0), (4096, 0)):      # ragged batches; more ways than records; 0 = work queue
+    for B, ways in ((1, 1), (5, 3), (777, 2), (4096, 2), (4096, 9), (4096, 16), (1, 0), (777, 0), (4096, 0)):      # ragged batches; more ways than records; 0 = work queue
         # (4096 robots x 7 records = 7168 units for the 2048 wavefronts that are resident at once; the replay starts from the queue the first launch put back)
         main(B, ways)
     main(8192, 0, R=5)
     main(777, 3, graph=True)
     main(4096, 0, graph=True)
+    main(4096, 16, R=20)                  # the geometry bench.py times by default: 16 ways, 20 records
     main(333, 0, R=3, horizon=200)
     main(333, 2, R=3, horizon=200)                                         # the shipped horizon: more than one 64-stage pass of the window
     main(64, 1, R=2, horizon=7)

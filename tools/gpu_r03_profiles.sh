@@ -45,12 +45,16 @@ python3 tools/pmc/summarize.py $O/pmc > $O/pmc_summary.json 2> $O/pmc_summary.er
 python3 tools/pmc/make_traffic.py $O/pmc_summary.json > $O/traffic.json 2> $O/traffic.err
 # the bench lines below quote roofline.traffic from profiles/traffic.json when its source hash is the current one: this run's own PMC passes
 [ -s $O/traffic.json ] && cp $O/traffic.json $R/profiles/traffic.json
+# (the raw per-dispatch counter CSVs are tens of MB with one input set per step: only the summaries travel back)
+rm -rf $O/pmc
 # bench lines (no profiler attached)
 timeout -k 10 400 python3 bench.py --steps 200 --warmup 20 > $O/bench_b4096.json 2> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench_b4096_driver.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --plan-ways 0 > $O/bench_b4096_driver_launch_per_step.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --plan-ways 0 > $O/bench_b4096_launch_per_step.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --plan-ways 2 > $O/bench_b4096_ways2.json 2>> $O/bench.err
+timeout -k 10 300 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --plan-ways 4 > $O/bench_b4096_ways4.json 2>> $O/bench.err
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --plan-ways 4 > $O/bench_b4096_driver_ways4.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 --batch 65536 --no-cpu-baseline > $O/bench_b65536.json 2>> $O/bench.err
 # (the card takes tens of ms of sustained load to reach its steady state at this batch size: the same line behind 100 and 300 warm-up steps)
 timeout -k 10 300 python3 bench.py --steps 100 --warmup 100 --batch 65536 --no-cpu-baseline > $O/bench_b65536_warmup100.json 2>> $O/bench.err
