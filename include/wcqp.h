@@ -294,6 +294,8 @@ int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch,
  * IK's lanes while its Jacobians are in flight - and `ways` wavefronts share a robot group, way w taking records w, w + ways,
  * ... (two ways fill both wave slots of every SIMD at the BASELINE batch of 4096).  Records of DIFFERENT ways run
  * concurrently: they must not share output arrays (give each way its own, like the pipelines of separate streams).
+ * ways = WCQP_PLAN_WAYS_AUTO picks the number of ways (enough workgroups for the hardware's dispatcher to even out the launch's ends: 16 at
+ * 4096 robots, 4 from 16384 on, never more than one per record); every record then needs output arrays of its own.
  * ways = 0 is the WORK-QUEUE form: the launch has as many wavefronts as are resident at once (2 per SIMD), and each takes the
  * next (record, robot group) unit - robot-group-major - from a device-side queue when it is done with one, so that no wave slot
  * idles while another wavefront still has records left (the tail of the fixed ways).  Any two records may then be in flight
@@ -306,6 +308,7 @@ int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch,
  * WCQP_E_UNSUPPORTED unless the IK handle runs its default kernel with jacobian_structure = WCQP_IK_JAC_MIXED: use
  * wcqp_qp_enqueue_steps then.  Same results as the single calls, bit for bit.  The arrays the
  * records point to must stay valid while the plan is used; the handles must outlive the plan. */
+#define WCQP_PLAN_WAYS_AUTO (-1)
 typedef struct wcqp_qp_plan_s* wcqp_qp_plan_t;
 int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_steps, const wcqp_qp_step* steps, int32_t ways,
                         wcqp_qp_plan_t* out);

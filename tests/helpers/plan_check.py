@@ -79,7 +79,7 @@ def main(B, ways, R=7, horizon=50, graph=False):
         r.x0, r.ref, r.ref_len, r.u_prev = m["x0"].data_ptr(), m["ref"].data_ptr(), N1, m["u_prev"].data_ptr()
         r.hull_A, r.hull_b, r.hull_nc = m["hull_A"].data_ptr(), m["hull_b"].data_ptr(), m["hull_nc"].data_ptr()
         r.u0, r.mpc_status, r.mpc_active, r.mpc_margin = o["u0"].data_ptr(), o["ms"].data_ptr(), o["ma"].data_ptr(), o["mm"].data_ptr()
-    mplan = wca.capi.QpPlan(mpc, None, B, mrecs, ways=max(1, ways))
+    mplan = wca.capi.QpPlan(mpc, None, B, mrecs, ways=(ways if ways != 0 else 1))
     mplan.enqueue(st.cuda_stream); mplan.enqueue(st.cuda_stream)
     torch.cuda.synchronize()
     for n, (a, b) in enumerate(zip(ref_o, mo)):
@@ -113,7 +113,7 @@ def main(B, ways, R=7, horizon=50, graph=False):
 
 
 if __name__ == "__main__":
-    for B, ways in ((1, 1), (5, 3), (777, 2), (4096, 2), (4096, 9), (4096, 16), (1, 0), (777, 0), (4096, 0)):      # ragged batches; more ways than records; 0 = work queue
+    for B, ways in ((1, 1), (5, 3), (777, 2), (4096, 2), (4096, 9), (4096, 16), (1, 0), (777, 0), (4096, 0), (777, -1), (4096, -1)):      # ragged batches; more ways than records; 0 = work queue; -1 = WCQP_PLAN_WAYS_AUTO
         # (4096 robots x 7 records = 7168 units for the 2048 wavefronts that are resident at once; the replay starts from the queue the first launch put back)
         main(B, ways)
     main(8192, 0, R=5)

@@ -84,6 +84,9 @@ def qp_enqueue_steps(mpc, ik, batch, steps):
     return done.value
 
 
+PLAN_WAYS_AUTO = -1
+
+
 class QpPlan:
     """wcqp_qp_plan_*: the records of qp_enqueue_steps uploaded once, replayed as ONE launch that walks through them; `ways`
     wavefronts share a robot group (way w takes records w, w + ways, ...: records of different ways need their own outputs);

@@ -619,7 +619,15 @@ extern "C" {
 
 int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_steps, const wcqp_qp_step* steps, int32_t ways,
                         wcqp_qp_plan_t* out) {
-    if (!out || batch < 1 || n_steps < 1 || !steps || ways < 0) return WCQP_E_INVALID;
+    if (!out || batch < 1 || n_steps < 1 || !steps || ways < WCQP_PLAN_WAYS_AUTO) return WCQP_E_INVALID;
+    if (ways == WCQP_PLAN_WAYS_AUTO) {
+        // enough workgroups for the dispatcher to even out the launch's ends: >= 16384 (8 x the resident wavefronts of an MI355X),
+        // at least 4 ways, at most one per record (bench.py's rule)
+        const int groups = (batch + 3) / 4;
+        ways = (16384 + groups - 1) / groups;
+        if (ways < 4) ways = 4;
+        if (ways > n_steps) ways = n_steps;
+    }
     // MPC-only plan: NO record has an IK part (J_left == NULL everywhere; `ik` may be NULL): BASELINE config 2 on its own
     bool mpc_only = true;
     for (int k = 0; k < n_steps; ++k) mpc_only = mpc_only && !steps[k].J_left;
