@@ -144,7 +144,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev& td, double (*smem)[PER_INST], int blk,
                 const int tick_now = 0, const bool do_mpc = true, const double* kmodel = nullptr, const double* gr_lds = nullptr,
-                MpcPairArgs* pm = nullptr, double* carry = nullptr)
+                MpcPairArgs* pm = nullptr, double* carry = nullptr, int* gait = nullptr)
 {
     static_assert(!(TICK && PAIR), "the tick kernel carries its own MPC chain");
     constexpr bool COMPACT = JSRC == 1;
@@ -267,11 +267,8 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 }
                 if (j < 8) { double* mh = S + K_MH + j * 3; mh[0] = mreg.ha.x; mh[1] = mreg.ha.y; mh[2] = mreg.hb; }
             }
-            {
-                const int side_ = ((tick_now + mreg.phase0) % (2 * td.step_ticks)) / td.step_ticks;     // 0: left is the stance foot
-                if (j < 12) S[K_SD + j] = state[inst * kStateLen + 24 + side_ * 12 + j];                // desired pose of the anchor sole: p (3), R (9)
-            }
-            const int side = ((tick_now + mreg.phase0) % (2 * td.step_ticks)) / td.step_ticks;
+            const int side = *gait >= td.step_ticks ? 1 : 0;          // (gait: this robot's cycle index (tick + phase0) % (2 step_ticks), carried from tick to tick) 0: left is the stance foot
+            if (j < 12) S[K_SD + j] = state[inst * kStateLen + 24 + side * 12 + j];                // desired pose of the anchor sole: p (3), R (9)
             const int cs[2] = {j, var1 ? col1 : 0};
             double* TW = S + K_TW;
             int kup[2][3], ksub[2];                 // the joints' pointer-jumping links and subtree ends: from the model table in LDS
@@ -575,12 +572,14 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             // MPC(t+1), ZMP-CoM law and plant of tick t + 1 for the same four robots, while the Jacobians are on their way
             if (do_mpc) {
                 // (hull rows in the MPC stash's place, just read back: the attached frames at 312..347 are still needed)
-                if constexpr (KINF) wcqp_tick::tick_mpc_finish_from(td, j, inst, live, tick_now + 1, mreg, m_r0, m_ux, m_uy, reinterpret_cast<double (*)[4]>(S + 348));
-                else wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL));
+                const int cyc1 = *gait + 1 == 2 * td.step_ticks ? 0 : *gait + 1;
+                const int code1 = wcqp_tick::contact_code_cyc(cyc1, td.step_ticks, td.ds_ticks);
+                if constexpr (KINF) wcqp_tick::tick_mpc_finish_from(td, j, inst, live, tick_now + 1, mreg, m_r0, m_ux, m_uy, reinterpret_cast<double (*)[4]>(S + 348), code1);
+                else wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL), nullptr, code1);
             }
             if (j < 6) {
-                const int code = wcqp_tick::contact_code(tick_now, mreg.phase0, td.step_ticks, td.ds_ticks);
-                const double tw = g_sw * wcqp_tick::swing_profile_at(td, mreg.phase0, tick_now);
+                const int code = wcqp_tick::contact_code_cyc(*gait, td.step_ticks, td.ds_ticks);
+                const double tw = g_sw * wcqp_tick::swing_profile_cyc(td, *gait);
                 g_twl = (code == 0 || code == 2) ? 0.0 : tw;
                 g_twr = (code == 1 || code == 2) ? 0.0 : tw;
             }
@@ -1550,11 +1549,13 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         }
         const int t0 = td.tick2[phase];
         double carry[4];                     // this lane's two joints: q_des, q_des, dq_prev, dq_prev
+        int gait;                            // this lane's robot: its gait cycle index (tick + phase0) % (2 step_ticks), advanced by one per tick
         {
             const int lane_ = threadIdx.x, j_ = lane_ & 15;
             const long ir = (long)blockIdx.x * 4 + (lane_ >> 4);
             const long i_ = ir < batch ? ir : (long)batch - 1;
             const bool v1_ = j_ < kDof - 16;
+            gait = (t0 + td.phase0[i_]) % (2 * td.step_ticks);
             carry[0] = td.q_des[i_ * kDof + j_]; carry[1] = td.q_des[i_ * kDof + (v1_ ? j_ + 16 : 0)];
             carry[2] = td.dq_prev[i_ * kDof + j_]; carry[3] = td.dq_prev[i_ * kDof + (v1_ ? j_ + 16 : 0)];
         }
@@ -1562,7 +1563,8 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         for (int k = 0; k < n_inner; ++k) {
             __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop (its registers are all spoken for)
             ik4_body<TICK, JSRC, false, LOG>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
-                                             (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains, nullptr, carry);
+                                             (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains, nullptr, carry, &gait);
+            gait = gait + 1 == 2 * td.step_ticks ? 0 : gait + 1;
             // tick t + 1 of this wave reads what tick t wrote (other lanes of the same wave): visible before it starts
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();

@@ -193,16 +193,13 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
                                                double& u0x, double& u0y, int& status, unsigned& active, double& margin_out)
 {
     nc = nc < 0 ? 0 : (nc > WCQP_HULL_ROWS ? WCQP_HULL_ROWS : nc);
-    double rn = 0.0;                                     // norm of this lane's own hull row (lanes 0..7)
-    if (t < WCQP_HULL_ROWS) {
-        rn = sqrt(fma(ray, ray, rax * rax));
-        s_hull[t][0] = rax; s_hull[t][1] = ray; s_hull[t][2] = rb; s_hull[t][3] = rn;
-    }
+    // 1 / |a| of this lane's own hull row (lanes 0..7; 0 for a zero row): the margin below divides by the norm
+    const double rn2 = fma(ray, ray, rax * rax);
+    const double irn = (t < WCQP_HULL_ROWS && rn2 > 0.0) ? wcqp::fast_rsqrt(rn2) : 0.0;
     // butterfly over the row (DPP, no LDS-pipe round trips): every lane ends with the same sum
 #define WCQP_SUM_STEP(C) ux += row_move<C>(ux); uy += row_move<C>(uy);
     WCQP_ROW_STEPS(WCQP_SUM_STEP)
 #undef WCQP_SUM_STEP
-    wcqp::wave_lds_fence();
 
     // ---- projection onto the polygon in the Sigma0^-1 metric --------------------------
     const double s00 = c.S0[0], s01 = c.S0[1], s10 = c.S0[2], s11 = c.S0[3];
@@ -215,9 +212,13 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
     // 37-candidate enumeration is skipped.  Same feasibility test as the enumeration applies to
     // candidate 0, so the result is identical either way.
     const bool row_violated = t < nc && row_res(rax, ray, rb, ux, uy) > c.feas_tol;
-    if (__ballot(row_violated) == 0ull) {
+    const bool none_violated = __ballot(row_violated) == 0ull;        // wave-uniform
+    if (none_violated) {
         best_cost = 0.0; best_id = 0;
-    } else
+    } else {
+    // the rows go to LDS only now: the enumeration is their one reader
+    if (t < WCQP_HULL_ROWS) { s_hull[t][0] = rax; s_hull[t][1] = ray; s_hull[t][2] = rb; s_hull[t][3] = irn; }
+    wcqp::wave_lds_fence();
     for (int id = t; id < kNumCand; id += kLanesPerInstance) {
         int e = -1, f = -1;
         if (id >= 1 && id <= 8) e = id - 1;
@@ -261,17 +262,20 @@ __device__ __forceinline__ void mpc_row_finish(const MpcDeviceConsts& c, int t, 
             best_cost = cost; best_x = px; best_y = py; best_mask = mask; best_id = id;
         }
     }
+    }
 #define WCQP_MIN_STEP(C) {                                                              \
         const double oc = row_move<C>(best_cost), ox = row_move<C>(best_x), oy = row_move<C>(best_y); \
         const int om = row_move<C>((int)best_mask), oi = row_move<C>(best_id);                 \
         if (oc < best_cost || (oc == best_cost && oi < best_id)) {                             \
             best_cost = oc; best_x = ox; best_y = oy; best_mask = (unsigned)om; best_id = oi;  \
         } }
-    WCQP_ROW_STEPS(WCQP_MIN_STEP)
+    // (after the early out every lane of a row already holds the same candidate 0 - u0_unc was all-reduced above - and the
+    // arg-min butterfly, 20 instructions a step, would only confirm it)
+    if (!none_violated) { WCQP_ROW_STEPS(WCQP_MIN_STEP) }
 #undef WCQP_MIN_STEP
     // signed distance to the hull boundary (computeMargin semantics): every row lane evaluates its
     // own row, row-min by DPP
-    double margin = (t < nc && rn > 0.0) ? -row_res(rax, ray, rb, best_x, best_y) / rn : std::numeric_limits<double>::infinity();
+    double margin = (t < nc && irn > 0.0) ? -row_res(rax, ray, rb, best_x, best_y) * irn : std::numeric_limits<double>::infinity();
 #define WCQP_MARGIN_STEP(C) margin = fmin(margin, row_move<C>(margin));
     WCQP_ROW_STEPS(WCQP_MARGIN_STEP)
 #undef WCQP_MARGIN_STEP

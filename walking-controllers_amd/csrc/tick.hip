@@ -167,6 +167,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     d.batch = params->batch; d.first = params->first; d.traj_len = params->max_ticks + N + 1;
     d.log_ticks = params->log_ticks > 0 ? params->log_ticks : 0;
     d.step_ticks = params->step_ticks; d.ds_ticks = params->ds_ticks;
+    d.inv_ss = d.step_ticks - d.ds_ticks > 0 ? 1.0 / (double)(d.step_ticks - d.ds_ticks) : 0.0;
     d.dT = params->mpc.sampling_time; d.k_com = params->k_com; d.k_zmp = params->k_zmp;
     d.noise = params->noise; d.seed = params->seed; d.com_height = params->mpc.com_height;
     d.omega = std::sqrt(params->mpc.gravity / params->mpc.com_height);

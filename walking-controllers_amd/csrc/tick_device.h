@@ -73,6 +73,8 @@ struct TickDev {
     // (WM/src/WalkingModule.cpp:800-810, column names :1231-1250), kept for the first logger_ticks ticks
     wcqp::GPtr<double> log_rows;   // [logger_ticks][B][kLoggerCols]
     int logger_ticks;
+    double inv_ss;      // 1 / (step_ticks - ds_ticks): the swing phase of a tick as a product (the tick kernel carries the gait cycle index
+                        // of its robots from tick to tick instead of dividing its way to it: ik4.hip)
     wcqp::GPtr<unsigned long long> stamps;     // diagnostic builds (-DWCQP_TICK_STAMPS): [workgroups][16] s_memtime at the phase boundaries; else NULL
 };
 constexpr int kHandLen = 14;
@@ -244,10 +246,10 @@ __device__ __forceinline__ void tick_mpc_partial(const TickDev& d, int j, long i
 }
 // r0: stage 0 of the window (the reference DCM of tick t; meaningful on lane 0)
 __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double2 r0, double ux, double uy,
-                                                     double (*s_hull)[4]) {
+                                                     double (*s_hull)[4], int code_known = -1) {
     // contact pair of tick t; the live row set follows it (WalkingController::setConvexHullConstraint switches rows only
     // when the pair changes, ...PredictiveController.cpp:369-374)
-    const int code = contact_code(t, R.phase0, d.step_ticks, d.ds_ticks);
+    const int code = code_known >= 0 ? code_known : contact_code(t, R.phase0, d.step_ticks, d.ds_ticks);
     const bool stale = code != R.built;
     if (__ballot(stale) != 0ull) {
         if (stale && live) {
@@ -312,10 +314,24 @@ __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, lo
 }
 template <bool GAINS_LDS = false>
 __device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double (*s_hull)[4],
-                                                const double* gr_lds = nullptr) {
+                                                const double* gr_lds = nullptr, int code_known = -1) {
     double ux, uy;
     tick_mpc_partial<GAINS_LDS>(d, j, inst, t, R, gr_lds, ux, uy);
-    tick_mpc_finish_from(d, j, inst, live, t, R, R.L.r[0], ux, uy, s_hull);
+    tick_mpc_finish_from(d, j, inst, live, t, R, R.L.r[0], ux, uy, s_hull, code_known);
+}
+// the same two with the gait cycle index cyc = (t + phase0) % (2 step_ticks) at hand (the tick kernel carries it from tick to tick:
+// integer divisions by run-time values are ~35 instructions each, and a tick had four of them, on every lane)
+__device__ __forceinline__ int contact_code_cyc(int cyc, int step_ticks, int ds_ticks) {
+    const bool second = cyc >= step_ticks;
+    const int s = second ? cyc - step_ticks : cyc;
+    return s < ds_ticks ? 2 : (second ? 1 : 0);
+}
+__device__ __forceinline__ double swing_profile_cyc(const TickDev& d, int cyc) {
+    if (!d.kin_mode) return 1.0;
+    const int sidx = cyc >= d.step_ticks ? cyc - d.step_ticks : cyc;
+    if (sidx < d.ds_ticks || d.step_ticks - d.ds_ticks < 1) return 0.0;
+    const double x = (double)(sidx - d.ds_ticks) * d.inv_ss;
+    return 10.392304845413264 * x * (1.0 - x) * (1.0 - 2.0 * x);
 }
 // swing_profile with the instance's phase offset already in a register
 __device__ __forceinline__ double swing_profile_at(const TickDev& d, int phase0, int t) {
