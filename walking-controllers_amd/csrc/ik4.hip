@@ -144,7 +144,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 unsigned* __restrict__ alo_out, unsigned* __restrict__ aup_out,
                 double* __restrict__ ferr_out, int* __restrict__ iters_out, const wcqp_tick::TickDev& td, double (*smem)[PER_INST], int blk,
                 const int tick_now = 0, const bool do_mpc = true, const double* kmodel = nullptr, const double* gr_lds = nullptr,
-                MpcPairArgs* pm = nullptr, double* carry = nullptr, int* gait = nullptr)
+                MpcPairArgs* pm = nullptr, double* carry = nullptr, int* gait = nullptr, const unsigned long long* noise_base = nullptr)
 {
     static_assert(!(TICK && PAIR), "the tick kernel carries its own MPC chain");
     constexpr bool COMPACT = JSRC == 1;
@@ -574,8 +574,8 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 // (hull rows in the MPC stash's place, just read back: the attached frames at 312..347 are still needed)
                 const int cyc1 = *gait + 1 == 2 * td.step_ticks ? 0 : *gait + 1;
                 const int code1 = wcqp_tick::contact_code_cyc(cyc1, td.step_ticks, td.ds_ticks);
-                if constexpr (KINF) wcqp_tick::tick_mpc_finish_from(td, j, inst, live, tick_now + 1, mreg, m_r0, m_ux, m_uy, reinterpret_cast<double (*)[4]>(S + 348), code1);
-                else wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL), nullptr, code1);
+                if constexpr (KINF) wcqp_tick::tick_mpc_finish_from(td, j, inst, live, tick_now + 1, mreg, m_r0, m_ux, m_uy, reinterpret_cast<double (*)[4]>(S + 348), code1, noise_base);
+                else wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL), nullptr, code1, noise_base);
             }
             if (j < 6) {
                 const int code = wcqp_tick::contact_code_cyc(*gait, td.step_ticks, td.ds_ticks);
@@ -1550,12 +1550,14 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         const int t0 = td.tick2[phase];
         double carry[4];                     // this lane's two joints: q_des, q_des, dq_prev, dq_prev
         int gait;                            // this lane's robot: its gait cycle index (tick + phase0) % (2 step_ticks), advanced by one per tick
+        unsigned long long nbase;            // ... and its share of the plant noise's hash (tick-independent)
         {
             const int lane_ = threadIdx.x, j_ = lane_ & 15;
             const long ir = (long)blockIdx.x * 4 + (lane_ >> 4);
             const long i_ = ir < batch ? ir : (long)batch - 1;
             const bool v1_ = j_ < kDof - 16;
             gait = (t0 + td.phase0[i_]) % (2 * td.step_ticks);
+            nbase = wcqp_tick::disturbance_base(td.seed, (unsigned long long)(td.first + i_));
             carry[0] = td.q_des[i_ * kDof + j_]; carry[1] = td.q_des[i_ * kDof + (v1_ ? j_ + 16 : 0)];
             carry[2] = td.dq_prev[i_ * kDof + j_]; carry[3] = td.dq_prev[i_ * kDof + (v1_ ? j_ + 16 : 0)];
         }
@@ -1563,7 +1565,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         for (int k = 0; k < n_inner; ++k) {
             __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop (its registers are all spoken for)
             ik4_body<TICK, JSRC, false, LOG>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
-                                             (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains, nullptr, carry, &gait);
+                                             (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains, nullptr, carry, &gait, &nbase);
             gait = gait + 1 == 2 * td.step_ticks ? 0 : gait + 1;
             // tick t + 1 of this wave reads what tick t wrote (other lanes of the same wave): visible before it starts
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

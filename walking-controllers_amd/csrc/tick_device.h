@@ -131,6 +131,12 @@ __device__ __forceinline__ double disturbance(unsigned long long seed, unsigned 
     const unsigned long long h = mix64(base + ((unsigned long long)(2 * tick + axis) + 1ull) * 0x94D049BB133111EBull);
     return (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
+// the same with the instance's share of the hash at hand (it does not depend on the tick: the tick kernel computes it once per launch)
+__device__ __forceinline__ unsigned long long disturbance_base(unsigned long long seed, unsigned long long inst) { return mix64(inst * 0x9E3779B97F4A7C15ull + seed); }
+__device__ __forceinline__ double disturbance_from(unsigned long long base, int tick, int axis) {
+    const unsigned long long h = mix64(base + ((unsigned long long)(2 * tick + axis) + 1ull) * 0x94D049BB133111EBull);
+    return (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
 
 __device__ __forceinline__ int contact_code(int t, int phase0, int step_ticks, int ds_ticks) {
     const int cyc = (t + phase0) % (2 * step_ticks);
@@ -246,7 +252,7 @@ __device__ __forceinline__ void tick_mpc_partial(const TickDev& d, int j, long i
 }
 // r0: stage 0 of the window (the reference DCM of tick t; meaningful on lane 0)
 __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double2 r0, double ux, double uy,
-                                                     double (*s_hull)[4], int code_known = -1) {
+                                                     double (*s_hull)[4], int code_known = -1, const unsigned long long* noise_base = nullptr) {
     // contact pair of tick t; the live row set follows it (WalkingController::setConvexHullConstraint switches rows only
     // when the pair changes, ...PredictiveController.cpp:369-374)
     const int code = code_known >= 0 ? code_known : contact_code(t, R.phase0, d.step_ticks, d.ds_ticks);
@@ -301,7 +307,8 @@ __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, lo
         const double p_star = p_star0 + 0.5 * d.dT * (v + v_star_prev);
         // synthetic plant: LIPM with a bounded disturbance
         const double com1 = com + d.dT * (-d.omega * (com - xi));
-        const double xi1 = d.a * xi + d.b * u + d.noise * disturbance(d.seed, (unsigned long long)(d.first + inst), t, ax);
+        const double w_ = noise_base ? disturbance_from(*noise_base, t, ax) : disturbance(d.seed, (unsigned long long)(d.first + inst), t, ax);
+        const double xi1 = d.a * xi + d.b * u + d.noise * w_;
         double2* sp = reinterpret_cast<double2*>(d.mst.get() + (inst * 2 + ax) * 8);
         sp[0] = make_double2(c_ref, vr); sp[1] = make_double2(com1, u); sp[2] = make_double2(p_star, v); sp[3] = make_double2(xi1, 0.0);
         // hand-off to the IK of tick t (desired CoM position / velocity, WalkingModule.cpp:686-695) + the plant state at the start of tick t
@@ -314,10 +321,10 @@ __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, lo
 }
 template <bool GAINS_LDS = false>
 __device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double (*s_hull)[4],
-                                                const double* gr_lds = nullptr, int code_known = -1) {
+                                                const double* gr_lds = nullptr, int code_known = -1, const unsigned long long* noise_base = nullptr) {
     double ux, uy;
     tick_mpc_partial<GAINS_LDS>(d, j, inst, t, R, gr_lds, ux, uy);
-    tick_mpc_finish_from(d, j, inst, live, t, R, R.L.r[0], ux, uy, s_hull, code_known);
+    tick_mpc_finish_from(d, j, inst, live, t, R, R.L.r[0], ux, uy, s_hull, code_known, noise_base);
 }
 // the same two with the gait cycle index cyc = (t + phase0) % (2 step_ticks) at hand (the tick kernel carries it from tick to tick:
 // integer divisions by run-time values are ~35 instructions each, and a tick had four of them, on every lane)
