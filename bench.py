@@ -412,7 +412,7 @@ def main():
     if first == 0 and NH == 50 and args.ik_form == "qpoases" and abs(args.ik_vmax - 0.5) < 1e-12 and not exch:
         try:
             gm = np.load(os.path.join(ROOT, "tests", "golden", "mpc_cfg2_b4096.npz"), allow_pickle=False)
-            gi = np.load(os.path.join(ROOT, "tests", "golden", "ik_qpoases_v050_b1024.npz"), allow_pickle=False)
+            gi = np.load(os.path.join(ROOT, "tests", "golden", "ik_qpoases_v050_b4096.npz"), allow_pickle=False)
             err, mism, rows_checked = 0.0, 0, 0
             last = args.warmup + args.steps - 1
             for p_ in range(P):
@@ -434,7 +434,7 @@ def main():
                 rows_checked += int(m.sum()) + int(n.sum())
             golden = {"golden_max_abs_err": err, "golden_active_set_mismatches": mism, "golden_rows_checked": rows_checked,
                       "golden": "every pipeline's last timed batch vs tests/golden/mpc_cfg2_b4096.npz (u0, active rows, status) and "
-                                "ik_qpoases_v050_b1024.npz (dq, active bounds, status); active sets where the strict-complementarity margin exceeds 1e-7"}
+                                "ik_qpoases_v050_b4096.npz (dq, active bounds, status); active sets where the strict-complementarity margin exceeds 1e-7"}
         except Exception as e:                      # a bench line without the check is still a bench line; say why
             golden["golden_error"] = repr(e)
 

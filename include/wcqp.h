@@ -20,8 +20,13 @@
  *     enqueue work and return without synchronising (graph-capturable: no
  *     allocation, no sync inside).  `*_host` entry points take HOST pointers,
  *     stage through the handle's own device buffers and synchronise.
- *   - the handle owns every buffer it allocates; the caller owns inputs/outputs;
- *     no pointer is retained past a call.  On the HOST side a handle is single-caller
+ *   - the handle owns every buffer it allocates; the caller owns inputs/outputs.
+ *     A solver handle (wcqp_mpc_t, wcqp_ik_t, wcqp_kin_t) and wcqp_qp_enqueue_steps retain no caller pointer past a
+ *     call.  Two objects DO, by design: a wcqp_qp_plan_t keeps the device pointers of every record it was created
+ *     from, and both solver handles, until wcqp_qp_plan_destroy (the caller keeps those arrays and handles alive and
+ *     their addresses unchanged for as long as the plan may be enqueued); a wcqp_tick_t owns its whole robot state on
+ *     the device and copies HOST inputs at the call that receives them (wcqp_tick_upload,
+ *     wcqp_tick_splice_reference: the host array may be released when the call returns).  On the HOST side a handle is single-caller
  *     (like the reference's solvers, which are only touched under WalkingModule's m_mutex,
  *     WM/src/WalkingModule.cpp:429): one thread at a time calls into it.  On the DEVICE
  *     side the work a `*_device` call (or wcqp_qp_enqueue_steps) enqueues only READS the
@@ -180,7 +185,11 @@ int wcqp_hull_from_feet_host(int32_t batch, const double* foot_rect,
 /* jacobian_structure: what the caller promises about the base blocks (columns 0..5) of the four Jacobians.
  * The reference always passes iDynTree free-floating Jacobians in MIXED representation
  * (WM/src/WalkingForwardKinematics.cpp:33, 436-454): J_left/J_right = [I B; 0 I | .], J_com = [I B | .],
- * J_neck (angular rows) = [0 I | .].  Algorithm 5 relies on that pattern and CHECKS it per instance (exact 1.0 / 0.0). */
+ * J_neck (angular rows) = [0 I | .].  Algorithm 5 relies on that pattern and CHECKS it per instance: every identity / zero
+ * entry within WCQP_IK_MIXED_TOL of 1.0 / 0.0 (a producer that forms the blocks through rotation products hands over
+ * 0.9999999999999999; such an entry is then TREATED as exact, which moves the solution by at most
+ * WCQP_IK_MIXED_TOL x |base velocity|).  Beyond the tolerance the instance does not have the pattern. */
+#define WCQP_IK_MIXED_TOL 1e-12
 #define WCQP_IK_JAC_AUTO    0    /* default: instances without the pattern are re-solved by the general kernel (one
                                     more, nearly empty, launch per call)                                          */
 #define WCQP_IK_JAC_MIXED   1    /* instances without the pattern come back WCQP_STATUS_STRUCTURE (dq = 0); one launch */
@@ -475,14 +484,19 @@ typedef struct wcqp_tick_s* wcqp_tick_t;
 int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out);
 int wcqp_tick_destroy(wcqp_tick_t h);
 int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in);                 /* also rewinds to tick 0 */
-/* enqueue only; use_graph: hipGraph replays of 8 ticks each, remainder as plain launches (ignored when the fused kernel runs
- * several ticks per launch: wcqp_tick_params.ticks_per_launch).  WCQP_E_INVALID when the ticks
- * enqueued since the last upload + n_ticks would exceed max_ticks (the trajectories end there). */
+/* enqueue only; use_graph: hipGraph replays of 8 ticks each, remainder as plain launches - IGNORED (no graph is built) whenever
+ * the fused kernel runs several ticks per launch, i.e. for every wcqp_tick_params.ticks_per_launch != 1 including the default 0,
+ * which makes a whole call ONE launch: a caller that needs the device back within a bound (another stream's work, a watchdog)
+ * caps it - ticks_per_launch = 256 keeps a launch of 8192 robots under 5 ms at no measurable cost.  WCQP_E_INVALID when the
+ * ticks enqueued since the last upload + n_ticks would exceed max_ticks (the trajectories end there).  A call that fails AFTER
+ * it has started to enqueue leaves the handle without a defined state: it then refuses to run until the next wcqp_tick_upload. */
 int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream);
 /* Trajectory merge (WM/src/WalkingModule.cpp:500-535, 1263-1308: a newly planned trajectory is spliced into the deques at a
  * merge point - 20 ticks ahead in the shipped configuration - and `resetTrajectory` is raised for exactly one tick): replaces
  * stages [from_tick, from_tick + n_stages) of every instance's DCM reference trajectory with ref_tail[B][n_stages][2] (HOST
- * pointer), in stream order behind the ticks already enqueued, while everything else of the pipeline stays as it is; later
+ * pointer; its rows are staged into device memory of the handle BEFORE the call returns - the caller may release or reuse
+ * ref_tail at once, whatever is still running on `stream`), in stream order behind the ticks already enqueued, while everything
+ * else of the pipeline stays as it is; later
  * ticks see the new stages through their windows [t, t + N].  from_tick >= the ticks enqueued so far, from_tick + n_stages <=
  * max_ticks + N + 1.  The reset flag itself has no counterpart: it makes MPCSolver::setGradient rebuild the gradient instead of
  * shifting it (MPCSolver.cpp:188-239), and this library always evaluates the gradient's contribution from the current window.

@@ -84,7 +84,8 @@ def contact_code(t: int, phase0: np.ndarray, p: TickParams) -> np.ndarray:
 
 
 def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, ik_form: str = "qpoases",
-              kin_model: dict | None = None, foot_rect=None, splices: dict | None = None, logger_ticks: int = 0):
+              kin_model: dict | None = None, foot_rect=None, splices: dict | None = None, logger_ticks: int = 0,
+              mpc_params: "qs.MPCParams | None" = None):
     """data: the arrays of walking-controllers_amd/synth.py::synth_tick_batch (or synth_walk_batch with
     `kin_model`).  Returns the per-tick logs u0[T][B][2], dq[T][B][23] and the final states.
 
@@ -108,7 +109,9 @@ def run_ticks(p: TickParams, data: dict, n_ticks: int, ik_params: qs.IKParams, i
         data["ref_traj"] = np.array(data["ref_traj"], copy=True)
     B = data["q0"].shape[0]
     N = p.horizon
-    mp = qs.MPCParams(horizon=N, sampling_time=p.dT, com_height=p.com_height, gravity=p.gravity)
+    # mpc_params: another robot's controllerParams.ini (Q, R; horizon / dT / CoM height must agree with `p`)
+    mp = mpc_params if mpc_params is not None else qs.MPCParams(horizon=N, sampling_time=p.dT, com_height=p.com_height, gravity=p.gravity)
+    assert mp.horizon == N and mp.sampling_time == p.dT and mp.com_height == p.com_height and mp.gravity == p.gravity
     c = qs.mpc_constants(mp)
     omega = np.sqrt(p.gravity / p.com_height)
     inst = np.arange(B, dtype=np.uint64) + np.uint64(data.get("first", 0))

@@ -64,8 +64,12 @@ def ik_golden(name, count, seed, form, v_max):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ik4096":              # only the full-batch config-3 golden (round 4)
+        ik_golden("ik_qpoases_v050_b4096.npz", 4096, 4321, "qpoases", 0.5)
+        sys.exit(0)
     mpc_golden("mpc_cfg2_b4096.npz", 4096, 1234)                       # BASELINE config 2
     mpc_golden("mpc_stress_b1024.npz", 1024, 77, uprev_sigma=0.04)     # hull rows active
     ik_golden("ik_qpoases_v050_b1024.npz", 1024, 4321, "qpoases", 0.5)
+    ik_golden("ik_qpoases_v050_b4096.npz", 4096, 4321, "qpoases", 0.5)   # BASELINE config 3 at its full batch: every row bench.py times
     ik_golden("ik_qpoases_v030_b512.npz", 512, 4321, "qpoases", 0.30)
     ik_golden("ik_osqp_b512.npz", 512, 4321, "osqp", 1.0)

@@ -40,7 +40,7 @@ def main():
     torch.cuda.synchronize()
     gd = os.path.join(ROOT, "tests", "golden")
     gm = np.load(os.path.join(gd, "mpc_cfg2_b4096.npz"), allow_pickle=False)
-    gi = np.load(os.path.join(gd, "ik_qpoases_v050_b1024.npz"), allow_pickle=False)
+    gi = np.load(os.path.join(gd, "ik_qpoases_v050_b4096.npz"), allow_pickle=False)
     sure_m = (gm["mu_min_active"] > MARGIN) & (gm["slack_min_inactive"] > MARGIN)
     sure_i = (gi["mu_min_active"] > MARGIN) & (gi["slack_min_inactive"] > MARGIN) & (gi["status"] == 0)
     o0 = outs[0]["dq"].cpu().numpy()

@@ -188,7 +188,7 @@ def _ik_solver(wca, form, vmax, algorithm=0):
 
 
 @pytest.mark.parametrize("algorithm", ALGS, ids=ALG_IDS)
-@pytest.mark.parametrize("name", ["ik_qpoases_v050_b1024.npz", "ik_qpoases_v030_b512.npz", "ik_osqp_b512.npz"])
+@pytest.mark.parametrize("name", ["ik_qpoases_v050_b1024.npz", "ik_qpoases_v050_b4096.npz", "ik_qpoases_v030_b512.npz", "ik_osqp_b512.npz"])
 def test_ik_matches_golden(wca, golden_dir, name, algorithm):
     g = _load(golden_dir, name)
     B, seed, form, vmax = int(g["count"]), int(g["seed"]), str(g["form"]), float(g["v_max"])
@@ -325,6 +325,63 @@ def test_ik_jacobian_structure_fallback(wca, qs):
     plain = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax).solve_host(b["J_left"], b["J_right"], b["J_neck"], b["J_com"], b["q"], b["state"])
     both = ok & (plain["status"] == 0)
     assert np.abs(plain["dq"][both] - auto["dq"][both]).max() <= 1e-9
+
+
+def test_ik_mixed_pattern_tolerance(wca, qs):
+    """A real producer forms the MIXED base blocks through rotation products (iDynTree, WM/src/WalkingForwardKinematics.cpp:33,
+    436-454): R R' is I only to rounding.  Identity / zero entries perturbed by +-1 ulp (and up to 1e-13) must stay on the
+    base-elimination kernel - SOLVED under WCQP_IK_JAC_MIXED, within 1e-9 of the oracle's optimum of the PERTURBED inputs, same
+    active sets - while a 1e-10 perturbation is past WCQP_IK_MIXED_TOL: STRUCTURE under MIXED, the general kernel under AUTO."""
+    B, vmax = 96, 0.4
+    rng = np.random.default_rng(17)
+    b = wca.synth.synth_ik_batch(B, seed=77)
+    p = qs.IKParams(v_max=vmax * np.ones(23))
+
+    def perturbed(eps_of):
+        bb = {k: np.array(v, copy=True) for k, v in b.items()}
+        for i in range(B):
+            for name, rows in (("J_left", 6), ("J_right", 6), ("J_com", 3), ("J_neck", 3)):
+                blk = bb[name][i][:, :6]
+                for r in range(rows):
+                    for c in range(6):
+                        # the pattern entries: identity diagonals and the zero blocks (the B blocks, columns 3..5 of linear rows, are data)
+                        lin_row = name != "J_neck" and r < 3
+                        if lin_row and c >= 3:
+                            continue
+                        blk[r, c] += eps_of(blk[r, c], rng)
+        return bb
+
+    ulp = lambda v, g: g.choice([-1.0, 0.0, 1.0]) * (np.spacing(1.0) if v != 0.0 else 1e-17)
+    tiny = lambda v, g: g.uniform(-1e-13, 1e-13)
+    for eps_of in (ulp, tiny):
+        bb = perturbed(eps_of)
+        assert any(not np.array_equal(bb[k], b[k]) for k in ("J_left", "J_right", "J_com", "J_neck"))
+        args = (bb["J_left"], bb["J_right"], bb["J_neck"], bb["J_com"], bb["q"], bb["state"])
+        mix = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, jacobian_structure=wca.IK_JAC_MIXED).solve_host(*args)
+        assert (mix["status"] != wca.STATUS_STRUCTURE).all()
+        n_checked = 0
+        for i in range(0, B, 3):
+            try:
+                r = qs.ik_exact(p, qs.ik_inputs_from_batch(bb, i), "qpoases")
+            except qs.QPInfeasible:
+                assert mix["status"][i] == wca.STATUS_INFEASIBLE
+                continue
+            assert mix["status"][i] == 0 and np.abs(mix["dq"][i] - r["dq"]).max() <= SOL_TOL
+            if r["mu_min_active"] > MARGIN and r["slack_min_inactive"] > MARGIN:
+                assert int(mix["active_lower"][i]) == sum(1 << j for j in r["lower"]) and int(mix["active_upper"][i]) == sum(1 << j for j in r["upper"])
+            n_checked += 1
+        assert n_checked >= 28
+    far = perturbed(lambda v, g: 1e-10)
+    args = (far["J_left"], far["J_right"], far["J_neck"], far["J_com"], far["q"], far["state"])
+    mix = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, jacobian_structure=wca.IK_JAC_MIXED).solve_host(*args)
+    assert (mix["status"] == wca.STATUS_STRUCTURE).all()
+    auto = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, jacobian_structure=wca.IK_JAC_AUTO).solve_host(*args)
+    gen = wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, jacobian_structure=wca.IK_JAC_GENERAL).solve_host(*args)
+    assert (auto["status"] != wca.STATUS_STRUCTURE).all() and np.array_equal(auto["dq"], gen["dq"])      # the general kernel solved them
+    for i in range(0, B, 8):
+        if auto["status"][i] == 0:
+            r = qs.ik_exact(p, qs.ik_inputs_from_batch(far, i), "qpoases")
+            assert np.abs(auto["dq"][i] - r["dq"]).max() <= SOL_TOL
 
 
 def test_ik_properties_at_full_size(wca):

@@ -443,9 +443,8 @@ class TickPipeline:
         """Trajectory merge: stages [from_tick, from_tick + n) of every instance's DCM reference <- ref_tail[B][n][2]."""
         tail = _f64(ref_tail)
         assert tail.ndim == 3 and tail.shape[0] == self.batch and tail.shape[2] == 2, tail.shape
+        # (the library stages the host rows before it returns: `tail` may go out of scope at once, whatever `stream` is still doing)
         check(lib().wcqp_tick_splice_reference(self._h, int(from_tick), tail.shape[1], _p(tail), stream or None), "wcqp_tick_splice_reference")
-        if stream:
-            stream_synchronize(stream)          # the host array must outlive the copy
 
     def download(self):
         B, L, D = self.batch, self.log_ticks, self.dof

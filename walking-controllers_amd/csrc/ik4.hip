@@ -82,6 +82,14 @@ static_assert(PER_INST * 8 * 4 * 12 <= 160 * 1024, "12 blocks per CU");
 #ifndef WCQP_IK4_WAVES
 #define WCQP_IK4_WAVES 2
 #endif
+// Register cap of ik_plan_kernel (the IK-only plan).  gfx90a and later have ONE register file of 512 entries per SIMD lane for VGPRs and
+// AGPRs together, allocated in blocks of 8, and hipcc's amdgpu_num_vgpr counts HALF of it: amdgpu_num_vgpr(108) caps the kernel at 216
+// VGPRs.  Two waves of 216 leave 80 registers of a SIMD free - room for ONE wave of mpc_plan_kernel (72) beside them.
+#ifdef WCQP_IK_PLAN_VGPR_HALF
+#define WCQP_IK_PLAN_REGS __attribute__((amdgpu_num_vgpr(WCQP_IK_PLAN_VGPR_HALF)))
+#else
+#define WCQP_IK_PLAN_REGS
+#endif
 #ifndef WCQP_IK4_KS
 #define WCQP_IK4_KS 4                 // bounds kept replicated in registers (more: the slot-per-lane loop)
 #endif
@@ -735,10 +743,14 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const int cm = lowc ? cb : cb - 3;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
+                // Within kMixedTol of the pattern counts as the pattern: a producer that forms the blocks through rotation products
+                // (R R' is I only to rounding) hands over 0.9999999999999999, and treating that entry as exactly 1 moves the
+                // solution by <= 1e-12 |v_base| - three orders inside the parity bar - instead of sending every instance to ik3.
                 const double id = (r == cm) ? 1.0 : 0.0;
-                const bool lo_ok = a1[r] == id && a1[3 + r] == 0.0 && a1[6 + r] == id && a1[9 + r] == 0.0 &&
-                                   a1[12 + r] == id && a1[15 + r] == 0.0;
-                const bool hi_ok = a1[3 + r] == id && a1[9 + r] == id && a1[15 + r] == id;
+                auto nr = [](double v, double w) { return fabs(v - w) <= kMixedTol; };        // (false for NaN)
+                const bool lo_ok = nr(a1[r], id) && nr(a1[3 + r], 0.0) && nr(a1[6 + r], id) && nr(a1[9 + r], 0.0) &&
+                                   nr(a1[12 + r], id) && nr(a1[15 + r], 0.0);
+                const bool hi_ok = nr(a1[3 + r], id) && nr(a1[9 + r], id) && nr(a1[15 + r], id);
                 pat = pat && (lowc ? lo_ok : hi_ok);
                 if (!lowc) { db[r * 3 + cm] = a1[6 + r] - a1[r]; db[9 + r * 3 + cm] = a1[12 + r] - a1[r]; }
             }
@@ -1719,7 +1731,7 @@ void qp_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcq
 }
 // an IK-only plan (no record has an MPC part: BASELINE config 3 on its own): the same walk without the MPC share, under a name of its
 // own so that profiles of the two do not mix
-__global__ __launch_bounds__(64, WCQP_IK4_WAVES)
+__global__ __launch_bounds__(64, WCQP_IK4_WAVES) WCQP_IK_PLAN_REGS
 void ik_plan_kernel(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups,
                     wcqp_mpc::MpcDeviceConsts c, unsigned* queue)
 {

@@ -9,6 +9,7 @@ namespace wcqp_ik {
 constexpr int kDof = 23;
 constexpr int kNV = kDof + 6;          // 29
 constexpr int kStateLen = WCQP_IK_STATE_LEN;
+constexpr double kMixedTol = WCQP_IK_MIXED_TOL;      // ik4.hip: how close to [I B; 0 I] a base block has to be (include/wcqp.h)
 
 struct IkDeviceParams {
     double lam[32];        // Lambda diagonal per variable (0 on the base)       base.cpp:64-67

@@ -69,6 +69,9 @@ void mpc_condensed_kernel(MpcDeviceConsts c, int batch,
 // solves robots 4g .. 4g+3 of records way, way + ways, ... - BASELINE config 2 (batched DCM-MPC, B = 4096) is 4.3 MB per batch, a
 // launch of its own is all ramp-up (5.7 us = 0.12 of the roofline); walked through in one launch, with the kernel's 65 registers
 // allowing seven waves per SIMD, the card has many batches' loads in flight.  The record's pointers come out of memory: as_global.
+#ifdef WCQP_MPC_PLAN_VGPR_HALF
+__attribute__((amdgpu_num_vgpr(WCQP_MPC_PLAN_VGPR_HALF)))       // (half the unified register file's count: ik4.hip, WCQP_IK_PLAN_VGPR_HALF)
+#endif
 __global__ __launch_bounds__(kBlock)
 void mpc_plan_kernel(MpcDeviceConsts c, int batch, const wcqp_qp_step* __restrict__ recs, int n_steps, int ways, int groups)
 {

@@ -74,6 +74,11 @@ struct wcqp_tick_s {
     KinTick kt{};
     int phase = 0;                // which copy of the tick index the next launch reads (TickDev::tick2): toggles per LAUNCH
     int ticks_per_launch = 1;     // > 1: the fused kernel walks through that many ticks per launch (no per-tick kinematics)
+    // wcqp_tick_splice_reference: the caller's host rows are staged HERE at call time (a copy stream of the handle's own, waited
+    // for before the call returns), the strided device-to-device copy then runs in the caller's stream order
+    double* splice_stage = nullptr; size_t splice_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t splice_done = nullptr; bool splice_pending = false;
 };
 
 namespace {
@@ -82,8 +87,8 @@ template <typename T>
 int dev_alloc(wcqp_tick_s* h, T** out, size_t count) {
     void* p = nullptr;
     if (hipMalloc(&p, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return WCQP_E_NOMEM;
+    h->allocs.push_back(p);              // owned from here on: wcqp_tick_destroy frees it whatever happens next
     if (hipMemset(p, 0, (count > 0 ? count : 1) * sizeof(T)) != hipSuccess) return WCQP_E_HIP;
-    h->allocs.push_back(p);
     *out = static_cast<T*>(p);
     return WCQP_OK;
 }
@@ -243,6 +248,9 @@ int wcqp_tick_destroy(wcqp_tick_t h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->splice_stage) (void)hipFree(h->splice_stage);
+    if (h->splice_done) (void)hipEventDestroy(h->splice_done);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->kin) wcqp_kin_destroy(h->kin);
     if (h->mpc) wcqp_mpc_destroy(h->mpc);
     if (h->ik) wcqp_ik_destroy(h->ik);
@@ -321,6 +329,11 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
     hipStream_t s = (hipStream_t)stream;
     if (n_ticks == 0) return WCQP_OK;
     int left = n_ticks;
+    // Everything that can be refused on the host is refused BEFORE anything is enqueued (the prime launch below already advances
+    // the MPC chain); an enqueue that fails after that leaves device state nobody can name - the handle then wants a new upload.
+    struct NeedsUpload { wcqp_tick_s* h; bool armed = true; ~NeedsUpload() { if (armed) h->uploaded = false; } } guard{h};
+    if (h->ticks_per_launch > 1 && !(h->fused && h->base_elim && (!h->kin || h->d.kin_fused))) { guard.armed = false; return WCQP_E_INVALID; }
+    if (h->d.skew && (!h->d_dev || !h->d.mst || !h->d.hand)) { guard.armed = false; return WCQP_E_INVALID; }
     if (h->d.skew) {
         // the fused launch of tick t carries IK(t) and MPC(t+1): the MPC of the call's first tick goes first, on its own, and
         // the call's LAST tick does not run the MPC of the tick after it - between calls nothing is ahead of anything
@@ -335,6 +348,7 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
             if (rc != WCQP_OK) return rc;
             h->phase ^= 1; h->ticks_enqueued += k; left -= k;
         }
+        guard.armed = false;
         return WCQP_OK;
     }
     if (h->d.skew) left -= 1;      // the last tick of the call is a plain launch of its own (below)
@@ -372,6 +386,7 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         if (rc != WCQP_OK) return rc;
         h->phase ^= 1; ++h->ticks_enqueued;
     }
+    guard.armed = false;
     return WCQP_OK;
 }
 
@@ -381,10 +396,27 @@ int wcqp_tick_splice_reference(wcqp_tick_t h, int32_t from_tick, int32_t n_stage
     // stages the ticks already enqueued have consumed as their own reference DCM stay as they are; everything a later
     // tick's window can see may change
     if (from_tick < h->ticks_enqueued || (long)from_tick + n_stages > (long)d.traj_len) return WCQP_E_INVALID;
+    // `ref_tail` is the caller's HOST memory and the copy below is ordered behind ticks that may still run for a long time: the
+    // rows are therefore taken NOW - staged into device memory of the handle on a copy stream of its own, waited for before
+    // this call returns - and the caller may release `ref_tail` as soon as it has.
+    const size_t bytes = (size_t)d.batch * (size_t)n_stages * 16;
+    if (!h->copy_stream) WCQP_HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->splice_done) WCQP_HIP_TRY(hipEventCreateWithFlags(&h->splice_done, hipEventDisableTiming));
+    if (h->splice_pending) { WCQP_HIP_TRY(hipEventSynchronize(h->splice_done)); h->splice_pending = false; }   // the previous merge has left the staging rows
+    if (bytes > h->splice_cap) {
+        if (h->splice_stage) { (void)hipFree(h->splice_stage); h->splice_stage = nullptr; h->splice_cap = 0; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return WCQP_E_NOMEM;
+        h->splice_stage = static_cast<double*>(p); h->splice_cap = bytes;
+    }
+    WCQP_HIP_TRY(hipMemcpyAsync(h->splice_stage, ref_tail, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    WCQP_HIP_TRY(hipStreamSynchronize(h->copy_stream));
     // strided copy: row i of the tail goes to stages [from_tick, from_tick + n_stages) of instance i, in stream order
     // behind the ticks already enqueued (the trajectory pointer the kernels - and any captured graph - hold does not change)
-    WCQP_HIP_TRY(hipMemcpy2DAsync(const_cast<double*>(d.ref_traj.get()) + (size_t)from_tick * 2, (size_t)d.traj_len * 16, ref_tail, (size_t)n_stages * 16,
-                                  (size_t)n_stages * 16, (size_t)d.batch, hipMemcpyHostToDevice, (hipStream_t)stream));
+    WCQP_HIP_TRY(hipMemcpy2DAsync(const_cast<double*>(d.ref_traj.get()) + (size_t)from_tick * 2, (size_t)d.traj_len * 16, h->splice_stage, (size_t)n_stages * 16,
+                                  (size_t)n_stages * 16, (size_t)d.batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    WCQP_HIP_TRY(hipEventRecord(h->splice_done, (hipStream_t)stream));
+    h->splice_pending = true;
     return WCQP_OK;
 }
 

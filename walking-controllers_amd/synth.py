@@ -226,9 +226,11 @@ def _rotz(a: np.ndarray) -> np.ndarray:
 
 
 def synth_ik_batch(count: int, seed: int = 4321, dof: int = 23, first: int = 0,
-                   joint_sigma: float = 0.3, com_sigma: float = 0.05):
+                   joint_sigma: float = 0.3, com_sigma: float = 0.05, additional_rotation=None, posture_deg=None):
     """SURVEY.md §8d config 3 (dense random joint columns, exact mixed-representation
-    base blocks).  Returns dict of C-contiguous arrays in ABI layout."""
+    base blocks).  Returns dict of C-contiguous arrays in ABI layout.
+    additional_rotation / posture_deg: another robot's qpInverseKinematics.ini values (default: iCubGazeboV2_5's; the
+    random draws do not depend on them)."""
     n = dof + 6
     rng = CounterRNG(seed, first, count)
     o = IK_STATE_OFFSETS
@@ -249,7 +251,7 @@ def synth_ik_batch(count: int, seed: int = 4321, dof: int = 23, first: int = 0,
     J_com[:, :, 3:6] = -_skew(pc)
     J_com[:, :, 6:] = rng.normal(3 * dof, com_sigma).reshape(count, 3, dof)
 
-    q_reg = np.deg2rad(ICUB_JOINT_REG_DEG if dof == 23 else np.zeros(dof))
+    q_reg = np.deg2rad((ICUB_JOINT_REG_DEG if posture_deg is None else np.asarray(posture_deg, float)) if dof == 23 else np.zeros(dof))
     q = q_reg[None, :] + rng.normal(dof, 0.05)
 
     state = np.zeros((count, IK_STATE_LEN))
@@ -263,7 +265,9 @@ def synth_ik_batch(count: int, seed: int = 4321, dof: int = 23, first: int = 0,
     R_right = _small_rot(rng.normal(3, 0.01)) @ Rd_right
     p_left = pd_left + rng.normal(3, 0.005)
     p_right = pd_right + rng.normal(3, 0.005)
-    Rd_neck = _rotz(yaw[:, 2]) @ np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    # setDesiredNeckOrientation right-multiplies additional_rotation (WM/src/WalkingQPInverseKinematics.cpp:143-146)
+    add_rot = np.array([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]) if additional_rotation is None else np.asarray(additional_rotation, float)
+    Rd_neck = _rotz(yaw[:, 2]) @ add_rot
     R_neck = _small_rot(rng.normal(3, 0.02)) @ Rd_neck
     com_des = 0.5 * (pd_left + pd_right) + np.array([0.0, 0.0, 0.53])
     com = com_des + rng.normal(3, 0.005)
@@ -313,7 +317,7 @@ def _dcm_reference(zl, zr, phase0, T, step_ticks, ds_ticks, dT, com_height, grav
 
 def synth_tick_batch(count: int, n_ticks: int, seed: int = 2718, horizon: int = 50, first: int = 0,
                      step_ticks: int = 180, ds_ticks: int = 110, dT: float = 0.01, com_height: float = 0.53,
-                     gravity: float = 9.81):
+                     gravity: float = 9.81, additional_rotation=None):
     """Inputs of the device-resident tick pipeline (BASELINE configs 4/5): per instance a long
     DCM reference trajectory (the deque the reference consumes one stage per tick), the
     support-polygon rows of the three contact pairs (left, right, both), a random phase
@@ -346,7 +350,7 @@ def synth_tick_batch(count: int, n_ticks: int, seed: int = 2718, horizon: int = 
     zl = left_xy + rot2(yaw[:, 0], (0.03, -0.005))            # leftZMPDelta
     zr = right_xy + rot2(yaw[:, 1], (0.03, 0.005))            # rightZMPDelta
     ref, zmp = _dcm_reference(zl, zr, phase0, T, step_ticks, ds_ticks, dT, com_height, gravity)
-    ik = synth_ik_batch(count, seed=seed + 1, first=first)
+    ik = synth_ik_batch(count, seed=seed + 1, first=first, additional_rotation=additional_rotation)
     dcm0 = ref[:, 0, :] + dcm_n
     return dict(first=first, ref_traj=ref, zmp_ref=zmp, hull_tab_A=hull_tab_A,
                 hull_tab_b=hull_tab_b, hull_tab_nc=hull_tab_nc, phase0=phase0, J_left=ik["J_left"],
