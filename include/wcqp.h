@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define WCQP_VERSION 302
+#define WCQP_VERSION 400
 
 /* return codes */
 #define WCQP_OK              0
@@ -323,6 +323,30 @@ int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_s
                         wcqp_qp_plan_t* out);
 int wcqp_qp_plan_enqueue(wcqp_qp_plan_t plan, void* stream);      /* enqueue only; graph-capturable */
 int wcqp_qp_plan_destroy(wcqp_qp_plan_t plan);
+
+/* =====================================================================================
+ * Shard slabs: the exchange format of the multi-GPU path (rank 0 scatters the inputs of every rank's block of
+ * robots, the ranks solve, rank 0 gathers the solutions).  All input arrays of a block live in ONE contiguous device buffer -
+ *     [x0 | ref | u_prev | hull_A | hull_b | hull_nc | J_left | J_right | J_neck | J_com | q | state]
+ * each in the layout of wcqp_mpc_solve_device / wcqp_ik_solve_device, every array starting on a 256-byte boundary - and all
+ * outputs in another - [u0 | mpc_margin | dq | mpc_status | mpc_active | ik_status | active_lower | active_upper | iters] - so
+ * that ONE ncclScatter (ncclSend / ncclRecv per peer) and ONE ncclGather move a step's data whatever the backend, and the solve
+ * kernels read the received bytes where they landed: wcqp_qp_step_from_slabs fills a step record with pointers INTO the two
+ * slabs (no unpack, no copy).  The reference has no counterpart (one robot per process, WM/include/WalkingModule.hpp:65-77).
+ * Pure host arithmetic: no device call, usable from any host language next to RCCL. */
+#define WCQP_SLAB_IN_ARRAYS  12
+#define WCQP_SLAB_OUT_ARRAYS 9
+typedef struct wcqp_slab_layout {
+    int32_t batch, ref_len;
+    int64_t in_offset[WCQP_SLAB_IN_ARRAYS];    /* byte offsets, in the order listed above */
+    int64_t in_bytes;                          /* size of an input slab (a multiple of 256)  */
+    int64_t out_offset[WCQP_SLAB_OUT_ARRAYS];
+    int64_t out_bytes;
+} wcqp_slab_layout;
+int wcqp_slab_layout_for(int32_t batch, int32_t ref_len, wcqp_slab_layout* out);
+/* step <- pointers into the slabs (streams NULL; foot_err NULL).  in_slab / out_slab: device addresses of buffers of at least
+ * in_bytes / out_bytes, at least 16-byte aligned (every hipMalloc is 256-byte aligned). */
+int wcqp_qp_step_from_slabs(const wcqp_slab_layout* layout, const void* in_slab, void* out_slab, wcqp_qp_step* step);
 
 /* =====================================================================================
  * Batched kinematics: forward kinematics of a kinematic tree and the free-floating

@@ -15,6 +15,11 @@ int orc_mpc_batch_osqp(const orc_mpc_params*, int, const double*, const double*,
 int orc_ik_batch(const orc_ik_params*, int, const double*, const double*, const double*, const double*, const double*,
                  const double*, double*, int*, uint32_t*, uint32_t*, int*, int);
 
+int orc_mpc_batch_condensed(int, const double*, const double*, const double*, const double*, double, int, const double*, const double*, int,
+                            const double*, const double*, const double*, const int*, double*, uint32_t*, int*, int);
+int orc_ik_batch_range_space(const orc_ik_params*, int, const double*, const double*, const double*, const double*, const double*,
+                             const double*, double*, int*, uint32_t*, uint32_t*, int*, int);
+
 static unsigned long long s_ = 88172645463325252ull;
 static double rnd(void) { s_ ^= s_ << 13; s_ ^= s_ >> 7; s_ ^= s_ << 17; return (double)(s_ >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
 
@@ -34,6 +39,14 @@ int main(void) {
     }
     int fail = orc_mpc_batch_osqp(&mp, B, x0, ref, N + 1, up, hA, hb, nc, u0, it, st, 2);
     printf("mpc fail %d u0[0] %.6f %.6f iters %d\n", fail, u0[0], u0[1], it[0]);
+    {   /* part (4): the condensed MPC with made-up (but well-formed) gains: this run is about memory safety, not values */
+        double Gr[(N + 1) * 4], Gx[4] = {0.6, 0, 0, 0.6}, Gu[4] = {0.1, 0, 0, 0.1}, S0[4] = {1e-7, 0, 0, 1e-7};
+        uint32_t act[B];
+        for (int k = 0; k <= N; ++k) { Gr[4 * k] = Gr[4 * k + 3] = 0.3 / (N + 1); Gr[4 * k + 1] = Gr[4 * k + 2] = 0.0; }
+        up[0] = 0.3;                                        /* pushes one instance out of its polygon */
+        fail = orc_mpc_batch_condensed(N, Gr, Gx, Gu, S0, 1e-10, B, x0, ref, N + 1, up, hA, hb, nc, u0, act, st, 2);
+        printf("mpc condensed fail %d u0[0] %.6f %.6f active %u\n", fail, u0[0], u0[1], act[0]);
+    }
     orc_ik_params ip; memset(&ip, 0, sizeof(ip));
     ip.dof = DOF; ip.use_com = 1; ip.k_pos_com = 1; ip.k_pos_foot = 4; ip.k_att_foot = 2; ip.k_neck = 1;
     for (int k = 0; k < 3; ++k) { ip.Wn[4 * k] = 5; ip.Wc[4 * k] = 100; }
@@ -59,6 +72,10 @@ int main(void) {
         ip.form = form;
         fail = orc_ik_batch(&ip, B, JL, JR, JN, JC, q, state, dq, st, lo, up2, it, 2);
         printf("ik form %d fail %d dq[0] %.6f iters %d\n", form, fail, dq[0], it[0]);
+        for (int j = 0; j < DOF; ++j) { ip.vmin[j] = form ? -0.4 : -0.08; ip.vmax[j] = form ? 0.4 : 0.08; }      /* tight: the active set walks */
+        fail = orc_ik_batch_range_space(&ip, B, JL, JR, JN, JC, q, state, dq, st, lo, up2, it, 2);
+        printf("ik range space form %d fail %d dq[0] %.6f iters %d\n", form, fail, dq[0], it[0]);
+        for (int j = 0; j < DOF; ++j) { ip.vmin[j] = -0.4; ip.vmax[j] = 0.4; }
     }
     return 0;
 }

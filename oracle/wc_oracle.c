@@ -937,6 +937,178 @@ int orc_ik_batch(const orc_ik_params* p, int batch,
     return nfail;
 }
 
+/* =====================================================================================
+ * (4) The SAME direct methods the device kernels run, in plain C on the host cores: bench.py times them as
+ * `cpu_baseline.same_algorithm_qps`, so that the record separates "a better algorithm" (condensing instead of ADMM, range
+ * space instead of a 29-variable active set) from "an MI355X".  Restated from this repository's own DESIGN.md 2 / 4.2
+ * (tools/ik4_proto.py is the numpy prototype of the IK part); checked against oracle/qp_spec.py in tests/test_cpu_oracle.py.
+ * ===================================================================================== */
+
+/* DCM-MPC, condensed: u0_unc = sum_i Gr_i r_i + Gx x0 + Gu u_prev (rows of the inverse of the constant equality KKT, computed by
+ * the caller), then the projection of u0_unc onto the support polygon in the Sigma0^-1 metric by enumeration of {no row, one
+ * row, two rows} active.  Returns the number of instances that are not SOLVED (status 2 = infeasible). */
+int orc_mpc_batch_condensed(int N, const double* Gr, const double* Gx, const double* Gu, const double* S0, double feas_tol, int batch,
+                            const double* x0, const double* ref, int ref_len, const double* u_prev,
+                            const double* hull_A, const double* hull_b, const int* hull_nc,
+                            double* u0_out, uint32_t* active_out, int* status_out, int nthreads) {
+    int nfail = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static) reduction(+ : nfail)
+#endif
+    for (int inst = 0; inst < batch; ++inst) {
+        const double* r = ref + (size_t)inst * ref_len * 2;
+        double ux = 0.0, uy = 0.0;
+        for (int i = 0; i <= N; ++i) {
+            const double* ri = r + 2 * (i < ref_len ? i : ref_len - 1);            /* MPCSolver.cpp:200-214 (constant tail) */
+            const double* g = Gr + 4 * i;
+            ux += g[0] * ri[0] + g[1] * ri[1]; uy += g[2] * ri[0] + g[3] * ri[1];
+        }
+        const double* xs = x0 + 2 * (size_t)inst; const double* up = u_prev + 2 * (size_t)inst;
+        ux += Gx[0] * xs[0] + Gx[1] * xs[1] + Gu[0] * up[0] + Gu[1] * up[1];
+        uy += Gx[2] * xs[0] + Gx[3] * xs[1] + Gu[2] * up[0] + Gu[3] * up[1];
+        const double* A = hull_A + (size_t)inst * 16; const double* b = hull_b + (size_t)inst * 8;
+        int nc = hull_nc[inst]; nc = nc < 0 ? 0 : (nc > 8 ? 8 : nc);
+        double best = INFINITY, bx = ux, by = uy; uint32_t bm = 0; int found = 0;
+        /* candidates: (e, f) with f == e meaning "row e alone" and e == -1 "no row"; first hit among equal costs wins */
+        for (int e = -1; e < nc; ++e) {
+            for (int f = e; f < nc; ++f) {
+                const int single = f == e;
+                double px = ux, py = uy, cost = 0.0; uint32_t mask = 0; int ok = 1;
+                if (e >= 0) {
+                    const double sex = S0[0] * A[2 * e] + S0[1] * A[2 * e + 1], sey = S0[2] * A[2 * e] + S0[3] * A[2 * e + 1];
+                    const double ree = A[2 * e] * sex + A[2 * e + 1] * sey, re = A[2 * e] * ux + A[2 * e + 1] * uy - b[e];
+                    mask = 1u << e;
+                    if (single) { ok = ree > 0.0; const double mu = ok ? re / ree : 0.0; px = ux - sex * mu; py = uy - sey * mu; cost = mu * re; }
+                    else {
+                        const double sfx = S0[0] * A[2 * f] + S0[1] * A[2 * f + 1], sfy = S0[2] * A[2 * f] + S0[3] * A[2 * f + 1];
+                        const double rff = A[2 * f] * sfx + A[2 * f + 1] * sfy, ref_ = A[2 * e] * sfx + A[2 * e + 1] * sfy;
+                        const double rf = A[2 * f] * ux + A[2 * f + 1] * uy - b[f], det = ree * rff - ref_ * ref_;
+                        ok = det > 1e-12 * ree * rff;                          /* parallel rows have no vertex */
+                        const double mue = ok ? (rff * re - ref_ * rf) / det : 0.0, muf = ok ? (ree * rf - ref_ * re) / det : 0.0;
+                        px = ux - sex * mue - sfx * muf; py = uy - sey * mue - sfy * muf; cost = mue * re + muf * rf; mask |= 1u << f;
+                    }
+                }
+                for (int k = 0; k < nc && ok; ++k) if (k != e && k != f && A[2 * k] * px + A[2 * k + 1] * py - b[k] > feas_tol) ok = 0;
+                if (ok && cost < best) { best = cost; bx = px; by = py; bm = mask; found = 1; }
+                if (e < 0) break;                                              /* "no row" is one candidate */
+            }
+        }
+        u0_out[2 * (size_t)inst] = bx; u0_out[2 * (size_t)inst + 1] = by;
+        if (active_out) active_out[inst] = bm;
+        if (status_out) status_out[inst] = found ? 0 : 2;
+        if (!found) nfail++;
+    }
+    return nfail;
+}
+
+/* QP-IK, base unknowns eliminated in closed form through the left-foot rows (MIXED free-floating Jacobians: base blocks
+ * [I B; 0 I]), the remaining 23-variable QP in range space: C = [L'(J_Nq - J_Lq,ang); A] (12 x 23), D = Lam^-1,
+ * M = C D C' + diag(I3, 0), M y = -(C D gq + [t; b']), x = -D (gq + C' y); joint-velocity bounds (qpOASES form) by the
+ * Goldfarb-Idnani dual active set on columns of P = D - D C' M^-1 C D.  CoM as constraint, every joint weight > 0.
+ * status: 0 solved, 1 max iterations, 2 infeasible, 4 numeric. */
+int orc_ik_batch_range_space(const orc_ik_params* p, int batch,
+                             const double* JLa, const double* JRa, const double* JNa, const double* JCa,
+                             const double* qa, const double* state,
+                             double* dq_out, int* status_out, uint32_t* act_lo, uint32_t* act_up, int* iters_out, int nthreads) {
+    enum { NJ = 23, NV = 29, NRW = 12 };
+    if (p->dof != NJ || !p->use_com) return -1;
+    double Lc[9];                                                          /* neck weight W = L L' */
+    memcpy(Lc, p->Wn, sizeof(Lc));
+    if (chol_dense(Lc, 3) != 0) return -1;
+    int nfail = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static) reduction(+ : nfail)
+#endif
+    for (int inst = 0; inst < batch; ++inst) {
+        const double* JL = JLa + (size_t)inst * 6 * NV; const double* JR = JRa + (size_t)inst * 6 * NV;
+        const double* JN = JNa + (size_t)inst * 3 * NV; const double* JC = JCa + (size_t)inst * 3 * NV;
+        const double* q = qa + (size_t)inst * NJ; const double* s = state + (size_t)inst * 87;
+        double bt[18];                                                     /* [b_L; b_R; b_C; e_neck] */
+        for (int foot = 0; foot < 2; ++foot) {
+            const double* pp = s + (foot ? 12 : 0); const double* R = s + (foot ? 15 : 3);
+            const double* pd = s + (foot ? 36 : 24); const double* Rd = s + (foot ? 39 : 27); const double* tw = s + (foot ? 81 : 75);
+            double e[3]; rot_err3(R, Rd, e);
+            const int skip = p->form == 1 && tw[0] == tw[1] && tw[0] == 0.0;
+            for (int k = 0; k < 3; ++k) {
+                bt[6 * foot + k] = skip ? tw[k] : tw[k] - p->k_pos_foot * (pp[k] - pd[k]);
+                bt[6 * foot + 3 + k] = skip ? tw[3 + k] : tw[3 + k] - p->k_att_foot * e[k];
+            }
+        }
+        for (int k = 0; k < 3; ++k) bt[12 + k] = s[72 + k] - p->k_pos_com * (s[66 + k] - s[69 + k]);
+        { double en[3]; rot_err3(s + 48, s + 57, en); const double kap = (p->form == 1 ? p->k_att_foot : 1.0) * (-p->k_neck); for (int k = 0; k < 3; ++k) bt[15 + k] = kap * en[k]; }
+        double dBR[9], dBC[9];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { dBR[3 * r + c] = JR[r * NV + 3 + c] - JL[r * NV + 3 + c]; dBC[3 * r + c] = JC[r * NV + 3 + c] - JL[r * NV + 3 + c]; }
+        double C[NRW][NJ + 1], D[NJ], gq[NJ];
+        for (int c = 0; c <= NJ; ++c) {                                    /* column c of [J_L; J_R; J_C; J_N | rhs] -> column c of [C | d] */
+            double a[18];
+            if (c < NJ) { for (int r = 0; r < 6; ++r) { a[r] = JL[r * NV + 6 + c]; a[6 + r] = JR[r * NV + 6 + c]; } for (int r = 0; r < 3; ++r) { a[12 + r] = JC[r * NV + 6 + c]; a[15 + r] = JN[r * NV + 6 + c]; } }
+            else memcpy(a, bt, sizeof(a));
+            const double* w = a + 3; const double n3[3] = {a[15] - w[0], a[16] - w[1], a[17] - w[2]};
+            for (int r = 0; r < 3; ++r) { double t = 0; for (int k = r; k < 3; ++k) t += Lc[3 * k + r] * n3[k]; C[r][c] = t; }        /* L' n */
+            for (int r = 0; r < 3; ++r) {
+                C[3 + r][c] = a[6 + r] - a[r] - (dBR[3 * r] * w[0] + dBR[3 * r + 1] * w[1] + dBR[3 * r + 2] * w[2]);
+                C[6 + r][c] = a[9 + r] - w[r];
+                C[9 + r][c] = a[12 + r] - a[r] - (dBC[3 * r] * w[0] + dBC[3 * r + 1] * w[1] + dBC[3 * r + 2] * w[2]);
+            }
+        }
+        for (int j = 0; j < NJ; ++j) { D[j] = 1.0 / p->w[j]; gq[j] = -p->w[j] * p->gains[j] * (p->qreg[j] - q[j]); }
+        double M[NRW * NRW], Mi[NRW * NRW], y[NRW], x[NJ];
+        for (int i = 0; i < NRW; ++i) for (int k = 0; k < NRW; ++k) { double t = (i == k && i < 3) ? 1.0 : 0.0; for (int j = 0; j < NJ; ++j) t += C[i][j] * D[j] * C[k][j]; M[i * NRW + k] = t; }
+        int rc = chol_dense(M, NRW) != 0 ? 4 : 0, it = 0; uint32_t lo = 0, up = 0;
+        if (rc == 0) {
+            for (int i = 0; i < NRW; ++i) { double t = C[i][NJ]; for (int j = 0; j < NJ; ++j) t += C[i][j] * D[j] * gq[j]; y[i] = -t; }
+            chol_solve(M, NRW, y);
+            for (int j = 0; j < NJ; ++j) { double t = gq[j]; for (int i = 0; i < NRW; ++i) t += C[i][j] * y[i]; x[j] = -D[j] * t; }
+            int need = 0;
+            if (p->form == 0) for (int j = 0; j < NJ; ++j) if (x[j] - p->vmax[j] > 1e-12 || p->vmin[j] - x[j] > 1e-12) need = 1;
+            if (need) {
+                double P[NJ][NJ], T[NRW][NJ];
+                for (int k = 0; k < NRW; ++k) { double e[NRW]; memset(e, 0, sizeof(e)); e[k] = 1.0; chol_solve(M, NRW, e); for (int i = 0; i < NRW; ++i) Mi[i * NRW + k] = e[i]; }
+                for (int i = 0; i < NRW; ++i) for (int j = 0; j < NJ; ++j) { double t = 0; for (int k = 0; k < NRW; ++k) t += Mi[i * NRW + k] * C[k][j]; T[i][j] = t * D[j]; }
+                for (int a = 0; a < NJ; ++a) for (int b2 = 0; b2 < NJ; ++b2) { double t = a == b2 ? D[a] : 0.0; for (int i = 0; i < NRW; ++i) t -= D[a] * C[i][a] * T[i][b2]; P[a][b2] = t; }
+                int W[NJ], nW = 0; double sg[NJ], mu[NJ], R[NJ * NJ], r[NJ], c[NJ], z[NJ]; char inW[NJ]; memset(inW, 0, sizeof(inW));
+                for (;;) {
+                    int pv = -1; double sv = 1e-12, sig = 1.0;
+                    for (int i = 0; i < NJ; ++i) { if (inW[i]) continue; const double vh = x[i] - p->vmax[i], vl = p->vmin[i] - x[i], v = vh > vl ? vh : vl; if (v > sv) { sv = v; pv = i; sig = vh >= vl ? 1.0 : -1.0; } }
+                    if (pv < 0) break;
+                    if (it >= 100) { rc = 1; break; }
+                    ++it;
+                    double mu_p = 0.0; int guard = 0;
+                    for (;;) {
+                        for (int a = 0; a < nW; ++a) { for (int b2 = 0; b2 < nW; ++b2) R[a * nW + b2] = sg[a] * sg[b2] * P[W[a]][W[b2]]; c[a] = sg[a] * sig * P[W[a]][pv]; }
+                        if (nW) { if (chol_dense(R, nW) != 0) { rc = 4; break; } memcpy(r, c, sizeof(double) * nW); chol_solve(R, nW, r); }
+                        for (int i = 0; i < NJ; ++i) { double zi = sig * P[i][pv]; for (int a = 0; a < nW; ++a) zi -= r[a] * sg[a] * P[i][W[a]]; z[i] = zi; }
+                        const double nz = sig * z[pv], t2 = (nW < NJ - 9 && nz > 1e-10 * P[pv][pv]) ? sv / nz : INFINITY;
+                        double t1 = INFINITY; int jd = -1;
+                        for (int a = 0; a < nW; ++a) if (r[a] > 0 && mu[a] / r[a] < t1) { t1 = mu[a] / r[a]; jd = a; }
+                        const double t = t1 < t2 ? t1 : t2;
+                        if (!(t < INFINITY)) { rc = 2; break; }
+                        for (int i = 0; i < NJ; ++i) x[i] -= t * z[i];
+                        for (int a = 0; a < nW; ++a) mu[a] -= t * r[a];
+                        mu_p += t; sv -= t * nz;
+                        if (t2 <= t1) { W[nW] = pv; sg[nW] = sig; mu[nW] = mu_p; inW[pv] = 1; ++nW; break; }
+                        inW[W[jd]] = 0;
+                        for (int a = jd; a < nW - 1; ++a) { W[a] = W[a + 1]; sg[a] = sg[a + 1]; mu[a] = mu[a + 1]; }
+                        --nW; ++it;
+                        if (++guard > NJ + 2) { rc = 1; break; }
+                    }
+                    if (rc != 0) break;
+                }
+                for (int a = 0; a < nW; ++a) { if (sg[a] > 0) { up |= 1u << W[a]; if (rc == 0) x[W[a]] = p->vmax[W[a]]; } else { lo |= 1u << W[a]; if (rc == 0) x[W[a]] = p->vmin[W[a]]; } }
+            }
+        }
+        for (int j = 0; j < NJ; ++j) dq_out[(size_t)inst * NJ + j] = rc == 0 ? x[j] : 0.0;
+        if (status_out) status_out[inst] = rc;
+        if (act_lo) act_lo[inst] = lo;
+        if (act_up) act_up[inst] = up;
+        if (iters_out) iters_out[inst] = it;
+        if (rc != 0) nfail++;
+    }
+    return nfail;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

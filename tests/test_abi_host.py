@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(wca):
     lib = wca.capi.lib()
     for s in declared:
         assert getattr(lib, s) is not None
-    assert lib.wcqp_version() == 302
+    assert lib.wcqp_version() == 400
     assert lib.wcqp_strerror(-4).decode().startswith("HIP")
 
 
@@ -152,6 +152,50 @@ def test_bench_gpus_n_starts_ranks_and_fails_with_them(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
                        env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_spawn_ranks_fails_fast_when_one_rank_dies(tmp_path):
+    """bench.spawn_ranks supervises ALL its children: a rank that dies before the rendezvous (a GPU fault, an OOM kill) takes the others
+    with it and the launcher exits non-zero at once - not after rank 0 has sat in init_process_group until its timeout.  Here rank 1
+    exits with code 3 immediately while rank 0 would sleep for ten minutes; a SIGTERM to the launcher is forwarded as well."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = tmp_path / "rank.py"
+    child.write_text("import os, sys, time\n"
+                     "open(os.path.join(%r, 'started_' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                     "if os.environ['RANK'] == '1' and '--die' in sys.argv: sys.exit(3)\n"
+                     "print('{\"rank0\": true}', flush=True)\n"
+                     "time.sleep(600)\n" % str(tmp_path))
+    launcher = tmp_path / "launch.py"
+    launcher.write_text("import sys\nsys.path.insert(0, %r)\nimport bench\nbench.spawn_ranks(2, argv=sys.argv[1:], script=%r)\n" % (root, str(child)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(launcher), "--die"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "rank exit codes" in r.stderr and "rank 1 ended first with 3" in r.stderr, r.stderr
+    assert time.time() - t0 < 30
+    assert "rank0" in r.stdout                                   # what rank 0 had printed is still relayed
+    pid0 = int((tmp_path / "started_0").read_text())
+    time.sleep(0.2)
+    with pytest.raises(ProcessLookupError):
+        os.kill(pid0, 0)                                         # rank 0 is gone, not orphaned
+    # SIGTERM to the launcher: both ranks are stopped
+    for f in ("started_0", "started_1"):
+        (tmp_path / f).unlink()
+    p = subprocess.Popen([sys.executable, str(launcher)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    for _ in range(200):
+        if (tmp_path / "started_0").exists() and (tmp_path / "started_1").exists():
+            break
+        time.sleep(0.05)
+    time.sleep(0.2)
+    pids = [int((tmp_path / f).read_text()) for f in ("started_0", "started_1")]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) != 0
+    time.sleep(0.2)
+    for pid in pids:
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
 
 
 def test_compact_jacobian_layout_of_the_icub_shaped_tree(wca):

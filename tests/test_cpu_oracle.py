@@ -204,3 +204,28 @@ def test_exact_oracle_says_infeasible_when_its_walk_ends_on_a_singular_set(qs, w
     b = wca.synth.synth_ik_batch(256, seed=seed)
     with pytest.raises(qs.QPInfeasible):
         qs.ik_exact(qs.IKParams(v_max=vmax * np.ones(23)), qs.ik_inputs_from_batch(b, i), "qpoases")
+
+
+def test_same_algorithm_cpu_legs_match_the_goldens(qs, wca, golden_dir):
+    """oracle/wc_oracle.c part (4): the device kernels' own direct methods in plain C (condensed MPC + 2-D projection; base-eliminated
+    range-space IK + dual active set) - what bench.py times as cpu_baseline.same_algorithm_qps - against the exact optimum."""
+    from oracle import c_oracle as co
+    mp = qs.MPCParams()
+    gains = co.mpc_condensed_gains(mp)
+    for name, kw in (("mpc_cfg2_b4096.npz", {}), ("mpc_stress_b1024.npz", {"uprev_sigma": 0.04})):
+        g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+        b = wca.synth.synth_mpc_batch(int(g["count"]), seed=int(g["seed"]), **kw)
+        u0, act, st = co.mpc_batch_condensed(mp, b, gains, nthreads=2)
+        assert (st == 0).all() and np.abs(u0 - g["u0"]).max() <= 1e-12
+        cc = (g["mu_min_active"] > 1e-7) & (g["slack_min_inactive"] > 1e-7)
+        assert np.array_equal(act[cc], g["active"][cc])
+    for name in ("ik_qpoases_v050_b4096.npz", "ik_qpoases_v030_b512.npz", "ik_osqp_b512.npz"):
+        g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+        b = wca.synth.synth_ik_batch(int(g["count"]), seed=int(g["seed"]))
+        p = qs.IKParams(v_max=float(g["v_max"]) * np.ones(23))
+        dq, st, lo, up, it = co.ik_batch_range_space(p, b, str(g["form"]), nthreads=2)
+        ok = g["status"] == 0
+        assert np.array_equal(st == 0, ok) and (st[~ok] == 2).all()
+        assert np.abs(dq[ok] - g["dq"][ok]).max() <= 1e-10
+        cc = (g["mu_min_active"] > 1e-7) & (g["slack_min_inactive"] > 1e-7) & ok
+        assert np.array_equal(lo[cc], g["active_lower"][cc]) and np.array_equal(up[cc], g["active_upper"][cc])

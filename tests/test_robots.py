@@ -133,9 +133,13 @@ def test_ik_against_oracle_on_every_robot(wca, qs, robot, form, vmax, algorithm)
 def test_tick_pipeline_on_every_robot(wca, qs, robot):
     """The closed-loop tick (constant Jacobians; the whole run in one launch) with each robot's controller parameters - MPC
     weights, CoM height, ZMP-CoM gains (zmpControllerParams.ini:7-8), IK weights / gains / neck rotation - against
-    oracle/tick_spec.py at 1e-9 over 150 ticks (more than one contact change per robot)."""
+    oracle/tick_spec.py at 1e-9 over 150 ticks (more than one contact change per robot).  The velocity limit is chosen per robot
+    so that bounds bind; with iCubGenova04's foot gains (k_posFoot 7, k_attFoot 5) the synthetic constant-Jacobian robots mostly
+    reach an infeasible IK within the run (10 of 12 in the oracle): the device must then stop the SAME robots on the SAME ticks -
+    this case doubles as the failure-path test at another parameter set."""
     from oracle import tick_spec as ts
-    B, T, vmax = 12, 150, 0.45
+    B, T = 12, 150
+    vmax = {"iCubGazeboV2_5": 0.45, "iCubGenova04": 1.2, "icubGazeboSim": 0.3}[robot]
     rb = robots.ROBOTS[robot]
     p = ts.TickParams(com_height=rb["com_height"], k_com=rb["k_com"], k_zmp=rb["k_zmp"])
     d = wca.synth.synth_tick_batch(B, T, com_height=rb["com_height"], additional_rotation=rb["additional_rotation"])
@@ -148,10 +152,11 @@ def test_tick_pipeline_on_every_robot(wca, qs, robot):
     assert out["tick"] == T
     assert np.array_equal(out["mpc_fail"], ref["mpc_fail"]) and np.array_equal(out["ik_fail"], ref["ik_fail"])
     ok = ref["ik_fail"] == 0
-    assert ok.sum() >= B - 2
+    assert ok.sum() >= (2 if robot == "iCubGenova04" else B)
+    assert ((ref["active_lower_log"] | ref["active_upper_log"]) != 0).any()          # bounds really bind
     assert np.abs(out["u0_log"] - ref["u0_log"]).max() <= 1e-9
-    assert np.abs(out["dq_log"][:, ok] - ref["dq_log"][:, ok]).max() <= 1e-8
-    assert np.abs(out["q_des"][ok] - ref["q_des"][ok]).max() <= 1e-9
+    assert np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8                        # stopped robots: dq = 0 on both sides
+    assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9
     assert np.abs(out["dcm"] - ref["dcm"]).max() <= 1e-9 and np.abs(out["com"] - ref["com"]).max() <= 1e-9
     assert np.array_equal(out["active_lower"][ok], ref["active_lower"][ok]) and np.array_equal(out["active_upper"][ok], ref["active_upper"][ok])
 

@@ -66,6 +66,99 @@ def test_world_size_2_gloo_matches_single_process(exchange):
     assert np.array_equal(got["lo"], lo.astype(np.int64)) and np.array_equal(got["up"], up.astype(np.int64))
 
 
+def _slab_worker(rank, world, port, q):
+    """The slab form of the exchange on CPU: ONE scatter of per-rank input slabs, the shard solved from the arrays where they
+    landed (the C oracle stands in for the HIP path, which reads the same addresses through the step record), ONE gather."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import walking_controllers_amd as wca
+    from oracle import c_oracle as co, qp_spec as qs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ip, mp = qs.IKParams(v_max=0.4 * np.ones(23)), qs.MPCParams()
+    gains = co.mpc_condensed_gains(mp)
+    calls = {"scatter": 0, "gather": 0}
+    real_scatter, real_gather = dist.scatter, dist.gather
+    dist.scatter = lambda *a, **k: (calls.__setitem__("scatter", calls["scatter"] + 1), real_scatter(*a, **k))[1]
+    dist.gather = lambda *a, **k: (calls.__setitem__("gather", calls["gather"] + 1), real_gather(*a, **k))[1]
+
+    def make(first, count):
+        bi = wca.synth.synth_ik_batch(count, seed=21, first=first)
+        bm = wca.synth.synth_mpc_batch(count, seed=22, first=first, uprev_sigma=0.04)
+        return {**{k: bi[k] for k in ("J_left", "J_right", "J_neck", "J_com", "q", "state")},
+                **{k: bm[k] for k in ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc")}}
+    holder = {}
+
+    def solve_step(rec, count):
+        sl = holder["sl"]
+        v = {k: t.numpy() for k, t in sl.in_views().items()}
+        # the step record points at exactly these arrays
+        assert rec.J_left == sl.in_views()["J_left"].data_ptr() and rec.state == sl.in_views()["state"].data_ptr()
+        assert rec.hull_nc == sl.in_views()["hull_nc"].data_ptr() and rec.ref_len == 51 and rec.dq == sl.out_views()["dq"].data_ptr()
+        dq, st, lo, up, it = co.ik_batch_range_space(ip, v, "qpoases", nthreads=1)
+        u0, act, mst = co.mpc_batch_condensed(mp, v, gains, nthreads=1)
+        o = sl.out_views()
+        o["dq"].copy_(torch.from_numpy(dq)); o["ik_status"].copy_(torch.from_numpy(st)); o["u0"].copy_(torch.from_numpy(u0))
+        o["active_lower"].copy_(torch.from_numpy(lo.view(np.int32))); o["active_upper"].copy_(torch.from_numpy(up.view(np.int32)))
+        o["mpc_status"].copy_(torch.from_numpy(mst)); o["mpc_active"].copy_(torch.from_numpy(act.view(np.int32)))
+    # (solve_sharded_slabs builds the slabs itself; the solver above needs to see them)
+    real_init = wca.sharding.ShardSlabs.__init__
+
+    def init(self, *a, **k):
+        real_init(self, *a, **k); holder["sl"] = self
+    wca.sharding.ShardSlabs.__init__ = init
+    out = wca.sharding.solve_sharded_slabs(dist, 64, 51, make, solve_step)
+    assert calls == {"scatter": 1, "gather": 1}, calls                # ONE collective each way per step
+    if rank == 0:
+        q.put({k: v for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_slab_exchange_matches_single_process():
+    """Two ranks, gloo, the slab form (wcqp_slab_layout_for / ShardSlabs): exactly one scatter and one gather, arrays used where
+    they landed, gathered result bitwise the single-process one."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import walking_controllers_amd as wca
+    from oracle import c_oracle as co, qp_spec as qs
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bi = wca.synth.synth_ik_batch(64, seed=21)
+    bm = wca.synth.synth_mpc_batch(64, seed=22, uprev_sigma=0.04)
+    dq, st, lo, up, _ = co.ik_batch_range_space(qs.IKParams(v_max=0.4 * np.ones(23)), bi, "qpoases", nthreads=1)
+    u0, act, mst = co.mpc_batch_condensed(qs.MPCParams(), bm, nthreads=1)
+    assert np.array_equal(got["dq"], dq) and np.array_equal(got["ik_status"], st) and np.array_equal(got["u0"], u0)       # bitwise
+    assert np.array_equal(got["active_lower"], lo) and np.array_equal(got["active_upper"], up)
+    assert np.array_equal(got["mpc_status"], mst) and np.array_equal(got["mpc_active"], act)
+
+
+def test_slab_layout_is_aligned_and_disjoint():
+    sys.path.insert(0, ROOT)
+    import walking_controllers_amd as wca
+    for B, n in ((1, 51), (4096, 51), (8191, 201), (65536, 51)):
+        L = wca.capi.SlabLayout.make(B, n)
+        for shapes, total in ((L.in_shapes(), L.in_bytes), (L.out_shapes(), L.out_bytes)):
+            end = 0
+            for k, (off, dt, shp) in shapes.items():
+                assert off % 256 == 0 and off >= end, (k, off, end)
+                end = off + int(np.prod(shp)) * np.dtype(dt).itemsize
+            assert end <= total and total % 256 == 0
+        # SURVEY 8d's algorithmic bytes of a robot-tick are 6296; the slabs add only the status words and padding
+        # (mpc_margin 8 B, hull_nc + six status / mask / iteration words 4 B each)
+        per = 6296 + (n - 51) * 16 + 8 + 7 * 4
+        assert per <= (L.in_bytes + L.out_bytes) / B < per + (21 * 256) / B + 1
+
+
 def test_shard_ranges_cover_the_batch():
     sys.path.insert(0, ROOT)
     import walking_controllers_amd as wca
@@ -132,7 +225,21 @@ def _gpu_worker(rank, world, port, exchange, q):
         return {"dq": oi["dq"], "status": oi["status"].astype(np.int64), "up": oi["active_upper"].astype(np.int64),
                 "lo": oi["active_lower"].astype(np.int64), "u0": om["u0"], "mstatus": om["status"].astype(np.int64)}
 
-    out = wca.sharding.solve_sharded(dist, 512, make, solve, exchange=exchange)
+    if exchange == "slabs":
+        # ONE scatter of per-rank slabs, the HIP solvers read / write the slabs in place through a step record, ONE gather
+        def make_slab(first, count):
+            d = make(first, count)
+            d["hull_nc"] = d["hull_nc"].astype(np.int32)
+            return d
+
+        def solve_step(rec, count):
+            assert wca.capi.qp_enqueue_steps(mpc, ik, count, (wca.capi.QpStep * 1)(rec)) == 1
+            torch.cuda.synchronize()
+        o = wca.sharding.solve_sharded_slabs(dist, 512, 51, make_slab, solve_step, device="cuda:0")
+        out = None if o is None else {"dq": o["dq"], "status": o["ik_status"].astype(np.int64), "up": o["active_upper"].astype(np.int64),
+                                      "lo": o["active_lower"].astype(np.int64), "u0": o["u0"], "mstatus": o["mpc_status"].astype(np.int64)}
+    else:
+        out = wca.sharding.solve_sharded(dist, 512, make, solve, exchange=exchange)
     if rank == 0:
         q.put({k: v for k, v in out.items()})
     dist.barrier()
@@ -140,7 +247,7 @@ def _gpu_worker(rank, world, port, exchange, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", [False, True])
+@pytest.mark.parametrize("exchange", [False, True, "slabs"])
 def test_two_ranks_on_the_gpu_match_single_process(wca, exchange):
     """the N > 1 path with the HIP solver - two spawned ranks (fresh processes, no exec of a
     GPU-initialised one) share the box's one GPU, rank 0 scatters the inputs and gathers the solutions over gloo
@@ -180,17 +287,25 @@ def test_bench_rccl_path_with_one_rank():
     with WORLD_SIZE = 1 makes bench.py initialise the process group on the device, scatter the inputs / gather the solutions
     every step (--exchange), all-reduce the timing and destroy the group - everything the N-GPU run does, with one rank."""
     env = dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WCQP_DIST_BACKEND="nccl")
-    r, line = _run_bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "512", "--exchange", "--no-cpu-baseline"], env)
+    r, line = _run_bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "512", "--exchange", "--no-cpu-baseline", "--no-tick"], env)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert line["n_gpus"] == 1 and "RCCL scatter/gather" in line["config"]["parallelism"]
+    assert line["n_gpus"] == 1 and "RCCL scatter / gather of per-rank slabs" in line["config"]["parallelism"]
     assert line["solved"]["ik"] == 512 and line["solved"]["mpc"] == 512
+    # the slab path, bitwise: what came back through scatter -> solve in place -> gather IS the golden optimum of the same rows
+    assert line["solved"]["golden_rows_checked"] == 1024 and line["solved"]["golden_active_set_mismatches"] == 0 and line["solved"]["golden_max_abs_err"] <= 1e-9
+    # ... and without --exchange a launcher-started run reports the exchange as a second pass (value stays the no-exchange number)
+    r, line = _run_bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "512", "--no-cpu-baseline", "--no-tick"], env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ex = line["exchange"]
+    assert ex["collectives_per_step"] == 2 and ex["backend"] == "nccl" and ex["gathered_ok"] is True and ex["bytes_per_step_per_peer"] > 512 * 6296
+    assert "no data-path collective" in line["config"]["parallelism"] and line["value"] > ex["value"]
 
 
 @pytest.mark.gpu
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher starts two ranks itself (the parent never touches the GPU) and reports
     n_gpus = 2; on this one-GPU box that is only allowed as a gloo REHEARSAL, and refused otherwise."""
-    args = ["--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "512", "--no-cpu-baseline"]
+    args = ["--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "512", "--no-cpu-baseline", "--no-tick"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     import json
     import subprocess
@@ -199,6 +314,7 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024
+    assert line["exchange"]["collectives_per_step"] == 2 and line["exchange"]["gathered_ok"] is True      # the slab exchange over gloo (staged through the host)
     sys.path.insert(0, ROOT)
     import walking_controllers_amd as wca
     if wca.device_count() < 2:

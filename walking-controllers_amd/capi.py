@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "wcqp_kin_create", "wcqp_kin_destroy", "wcqp_kin_jacobians_device", "wcqp_kin_jacobians_host",
     "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download", "wcqp_tick_splice_reference",
     "wcqp_qp_enqueue_steps", "wcqp_qp_plan_create", "wcqp_qp_plan_enqueue", "wcqp_qp_plan_destroy",
+    "wcqp_slab_layout_for", "wcqp_qp_step_from_slabs",
 )
 
 
@@ -73,6 +74,41 @@ class QpStep(C.Structure):
                 ("q", C.c_void_p), ("state", C.c_void_p),
                 ("dq", C.c_void_p), ("ik_status", C.c_void_p), ("active_lower", C.c_void_p), ("active_upper", C.c_void_p),
                 ("foot_err", C.c_void_p), ("iters", C.c_void_p), ("ik_stream", C.c_void_p)]
+
+
+SLAB_IN = ("x0", "ref", "u_prev", "hull_A", "hull_b", "hull_nc", "J_left", "J_right", "J_neck", "J_com", "q", "state")
+SLAB_OUT = ("u0", "mpc_margin", "dq", "mpc_status", "mpc_active", "ik_status", "active_lower", "active_upper", "iters")
+
+
+class SlabLayout(C.Structure):
+    """wcqp_slab_layout: where the arrays of one rank's block of robots sit inside its input / output slab (include/wcqp.h)."""
+    _fields_ = [("batch", C.c_int32), ("ref_len", C.c_int32), ("in_offset", C.c_int64 * len(SLAB_IN)), ("in_bytes", C.c_int64),
+                ("out_offset", C.c_int64 * len(SLAB_OUT)), ("out_bytes", C.c_int64)]
+
+    @classmethod
+    def make(cls, batch, ref_len):
+        L = cls()
+        check(lib().wcqp_slab_layout_for(int(batch), int(ref_len), C.byref(L)), "wcqp_slab_layout_for")
+        return L
+
+    def in_shapes(self):
+        """name -> (byte offset, numpy dtype, shape) of the input slab's arrays."""
+        B, n = self.batch, self.ref_len
+        shp = dict(x0=(B, 2), ref=(B, n, 2), u_prev=(B, 2), hull_A=(B, HULL_ROWS, 2), hull_b=(B, HULL_ROWS), hull_nc=(B,), J_left=(B, 6, 29),
+                   J_right=(B, 6, 29), J_neck=(B, 3, 29), J_com=(B, 3, 29), q=(B, 23), state=(B, IK_STATE_LEN))
+        return {k: (int(self.in_offset[i]), np.int32 if k == "hull_nc" else np.float64, shp[k]) for i, k in enumerate(SLAB_IN)}
+
+    def out_shapes(self):
+        B = self.batch
+        f64 = dict(u0=(B, 2), mpc_margin=(B,), dq=(B, 23))
+        return {k: (int(self.out_offset[i]), np.float64 if k in f64 else (np.int32 if k in ("mpc_status", "ik_status", "iters") else np.uint32), f64.get(k, (B,)))
+                for i, k in enumerate(SLAB_OUT)}
+
+    def step(self, in_slab: int, out_slab: int) -> "QpStep":
+        """A step record whose pointers point INTO the two slabs (raw device addresses)."""
+        r = QpStep()
+        check(lib().wcqp_qp_step_from_slabs(C.byref(self), C.c_void_p(in_slab), C.c_void_p(out_slab), C.byref(r)), "wcqp_qp_step_from_slabs")
+        return r
 
 
 def qp_enqueue_steps(mpc, ik, batch, steps):
@@ -186,6 +222,8 @@ def lib() -> C.CDLL:
         L.wcqp_qp_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.c_int32, C.POINTER(C.c_void_p)]
         L.wcqp_qp_plan_enqueue.argtypes = [C.c_void_p, C.c_void_p]
         L.wcqp_qp_plan_destroy.argtypes = [C.c_void_p]
+        L.wcqp_slab_layout_for.argtypes = [C.c_int32, C.c_int32, C.POINTER(SlabLayout)]
+        L.wcqp_qp_step_from_slabs.argtypes = [C.POINTER(SlabLayout), C.c_void_p, C.c_void_p, C.POINTER(QpStep)]
         _lib = L
     return _lib
 

@@ -103,6 +103,42 @@ int wcqp_qp_enqueue_steps(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n
     return WCQP_OK;
 }
 
+// ---- shard slabs (include/wcqp.h): the multi-GPU exchange format; host arithmetic only
+int wcqp_slab_layout_for(int32_t batch, int32_t ref_len, wcqp_slab_layout* out) {
+    if (!out || batch < 1 || ref_len < 1) return WCQP_E_INVALID;
+    const int64_t B = batch;
+    const int64_t in_sz[WCQP_SLAB_IN_ARRAYS] = {B * 2 * 8, B * ref_len * 2 * 8, B * 2 * 8, B * WCQP_HULL_ROWS * 2 * 8, B * WCQP_HULL_ROWS * 8, B * 4,
+                                                B * 6 * 29 * 8, B * 6 * 29 * 8, B * 3 * 29 * 8, B * 3 * 29 * 8, B * 23 * 8, B * WCQP_IK_STATE_LEN * 8};
+    const int64_t out_sz[WCQP_SLAB_OUT_ARRAYS] = {B * 2 * 8, B * 8, B * 23 * 8, B * 4, B * 4, B * 4, B * 4, B * 4, B * 4};
+    out->batch = batch; out->ref_len = ref_len;
+    int64_t off = 0;
+    for (int k = 0; k < WCQP_SLAB_IN_ARRAYS; ++k) { out->in_offset[k] = off; off += (in_sz[k] + 255) / 256 * 256; }
+    out->in_bytes = off;
+    off = 0;
+    for (int k = 0; k < WCQP_SLAB_OUT_ARRAYS; ++k) { out->out_offset[k] = off; off += (out_sz[k] + 255) / 256 * 256; }
+    out->out_bytes = off;
+    return WCQP_OK;
+}
+
+int wcqp_qp_step_from_slabs(const wcqp_slab_layout* L, const void* in_slab, void* out_slab, wcqp_qp_step* s) {
+    if (!L || !in_slab || !out_slab || !s || L->batch < 1 || L->ref_len < 1) return WCQP_E_INVALID;
+    if (((uintptr_t)in_slab | (uintptr_t)out_slab) & 15u) return WCQP_E_INVALID;        // 16-byte vector loads; the arrays inside sit on 256-byte offsets
+    const char* in = static_cast<const char*>(in_slab);
+    char* o = static_cast<char*>(out_slab);
+    auto d = [&](int k) { return reinterpret_cast<const double*>(in + L->in_offset[k]); };
+    *s = wcqp_qp_step{};
+    s->x0 = d(0); s->ref = d(1); s->ref_len = L->ref_len; s->u_prev = d(2); s->hull_A = d(3); s->hull_b = d(4);
+    s->hull_nc = reinterpret_cast<const int32_t*>(in + L->in_offset[5]);
+    s->J_left = d(6); s->J_right = d(7); s->J_neck = d(8); s->J_com = d(9); s->q = d(10); s->state = d(11);
+    s->u0 = reinterpret_cast<double*>(o + L->out_offset[0]); s->mpc_margin = reinterpret_cast<double*>(o + L->out_offset[1]);
+    s->dq = reinterpret_cast<double*>(o + L->out_offset[2]);
+    s->mpc_status = reinterpret_cast<int32_t*>(o + L->out_offset[3]); s->mpc_active = reinterpret_cast<uint32_t*>(o + L->out_offset[4]);
+    s->ik_status = reinterpret_cast<int32_t*>(o + L->out_offset[5]);
+    s->active_lower = reinterpret_cast<uint32_t*>(o + L->out_offset[6]); s->active_upper = reinterpret_cast<uint32_t*>(o + L->out_offset[7]);
+    s->iters = reinterpret_cast<int32_t*>(o + L->out_offset[8]);
+    return WCQP_OK;
+}
+
 int wcqp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
