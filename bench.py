@@ -671,13 +671,15 @@ def bench_qp(c):
 
 # ------------------------------------------------------------------------------------------------- configs[3] / [4]: the closed-loop tick
 def tick_measure(c, B, T, W, kin_mode, first=0, handoff="fused", ticks_per_launch=0, n_groups=1, hot_start=True, ik_form="qpoases",
-                 vmax_tables=0.5, graph=True, check_ticks=16):
+                 vmax_tables=0.5, graph=True, check_ticks=16, external=False):
     """One closed-loop run: B robots per GPU, W warm-up ticks (the first `check_ticks` of them logged and replayed through
     oracle/tick_spec.py for a sample of robots), then T timed ticks in ONE wcqp_tick_run call per robot group.
+    external: wcqp_tick_params.plant = EXTERNAL - every tick behind a wcqp_tick_set_feedback_device call and a run call of its own (the
+    measured state fed here is the robots' initial one, held: this run prices the mode, the parity of it is tests/test_tick_pipeline.py's).
     Returns (results, elapsed seconds MAX over ranks)."""
     torch, wca, dev, dist = c.torch, c.wca, c.dev, c.dist
     S_ = wca.synth
-    L = min(check_ticks, W)
+    L = 0 if external else min(check_ticks, W)
     vmax = S_.WALK_VMAX if kin_mode else vmax_tables * np.ones(23)
     form = wca.IK_FORM_QPOASES if ik_form == "qpoases" else wca.IK_FORM_OSQP
     kin = wca.KinModel(S_.icub_like_model()) if kin_mode else None
@@ -694,8 +696,10 @@ def tick_measure(c, B, T, W, kin_mode, first=0, handoff="fused", ticks_per_launc
             data = S_.synth_tick_batch(cnt, T + W, first=f0)
             iks = wca.IkSolver(form=form, v_max=vmax)
         pp = wca.TickPipeline(cnt, T + W, wca.MpcSolver(horizon=50), iks, first=f0, kin=kin, ik_hot_start=hot_start, log_ticks=L,
-                              kin_handoff={"fused": 0, "dense": 1, "compact": 2}[handoff], ticks_per_launch=ticks_per_launch)
+                              kin_handoff={"fused": 0, "dense": 1, "compact": 2}[handoff], ticks_per_launch=ticks_per_launch, external_feedback=external)
         pp.upload(data)
+        if external:
+            pp._fb = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("dcm0", "com0", "u_init")]
         pipes.append(pp); datas.append((f0, cnt, data))
     stream = torch.cuda.current_stream(dev)
     streams = [stream] + [torch.cuda.Stream(dev) for _ in pipes[1:]]
@@ -708,7 +712,12 @@ def tick_measure(c, B, T, W, kin_mode, first=0, handoff="fused", ticks_per_launc
 
     def run(n):
         for pp, st in zip(pipes, streams):
-            pp.run(n, use_graph=graph, stream=st.cuda_stream)
+            if external:
+                for _ in range(n):
+                    pp.set_feedback_device(pp._fb[0].data_ptr(), pp._fb[1].data_ptr(), pp._fb[2].data_ptr(), 0, st.cuda_stream)
+                    pp.run(1, use_graph=False, stream=st.cuda_stream)
+            else:
+                pp.run(n, use_graph=graph, stream=st.cuda_stream)
     if W > 0:
         run(W)
     barrier()
@@ -796,6 +805,18 @@ def tick_object(c):
             }
         except Exception as e:
             obj[name] = {"error": repr(e)}
+    # what the EXTERNAL-feedback mode costs: a feedback copy + the MPC of the tick + its IK as three launches per tick, one run call per tick
+    try:
+        Te = min(T, 200)
+        r, elapsed = tick_measure(c, B, Te, 8, True, first=c.rank * B, external=True)
+        obj["external_feedback"] = {
+            "value": (2 * B * world * Te - int(round(reduce_over_ranks(c, float(r["stopped"]), "sum")))) / elapsed, "unit": "QP/s", "ticks": Te,
+            "us_per_tick": 1e6 * elapsed / Te, "kernel_us_per_tick": 1e3 * r["dev_ms"], "per_tick_kinematics": True,
+            "launch": "per tick: tick_feedback_kernel + tick_mpc_prime_kernel<EXT> + ik4_kernel<TICK, fused kinematics, EXT> (wcqp_tick_set_feedback_device + wcqp_tick_run(1))",
+            "what": "wcqp_tick_params.plant = EXTERNAL: every tick reads the caller's measured DCM / CoM / ZMP from device arrays, in order (no MPC ahead of its feedback); "
+                    "the measured state fed here is the initial one, held", "robots_with_ik_fail": int((r["ik_fail"] > 0).sum())}
+    except Exception as e:
+        obj["external_feedback"] = {"error": repr(e)}
     return obj
 
 

@@ -474,7 +474,17 @@ typedef struct wcqp_tick_params {
      *   the twelve - residuals of equality constraints, O(1e-15) in the reference too - are logged as zeros).
      * Runs a logging build of the tick kernel (the default IK kernel only); a debugging aid like the reference's dumpData. */
     int32_t logger_ticks;
+    /* Where a tick's MEASURED state comes from (WCQP_TICK_PLANT_*).  INTERNAL (0, default): the synthetic LIPM plant of the harness
+     * (measured DCM follows xi+ = a xi + b u0 + w, measured CoM c+ = c + dT (-omega (c - xi)), measured ZMP = the previous command,
+     * measured joints = the desired ones).  EXTERNAL: the caller's - B robots simulated or measured by something else - handed over on
+     * the device before every tick with wcqp_tick_set_feedback_device; what the reference reads from the robot every tick:
+     * setFeedback(measuredDCM) WM/src/WalkingModule.cpp:612, WalkingZMPController::setFeedback(measuredZMP, measuredCoM) :665, the
+     * measured joint positions of WalkingQPIK::setRobotState :373.  A tick then cannot run ahead of its feedback: wcqp_tick_run takes
+     * exactly ONE tick per call, in order (MPC(t), then IK(t): 2 launches + the feedback copy).  Default IK kernel only. */
+    int32_t plant;
 } wcqp_tick_params;
+#define WCQP_TICK_PLANT_INTERNAL 0
+#define WCQP_TICK_PLANT_EXTERNAL 1
 
 typedef struct wcqp_tick_inputs {   /* HOST pointers, copied at upload */
     const double* ref_traj;     /* [B][max_ticks+N+1][2]                                      */
@@ -527,6 +537,15 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
  * Valid between wcqp_tick_run calls (a call leaves nothing running ahead); captured graphs stay valid - the trajectory
  * buffer does not move. */
 int wcqp_tick_splice_reference(wcqp_tick_t h, int32_t from_tick, int32_t n_stages, const double* ref_tail, void* stream);
+/* External feedback (wcqp_tick_params.plant = WCQP_TICK_PLANT_EXTERNAL): the measured state the NEXT tick is to use - DEVICE
+ * pointers, dcm_meas / com_meas / zmp_meas [B][2], q_meas [B][dof] or NULL (= the desired joint positions, as with the internal
+ * plant).  Enqueues one small copy kernel on `stream`: the arrays may be reused once it has run (stream order), nothing is
+ * retained.  Required before every wcqp_tick_run call of such a handle (which then takes n_ticks = 1: WCQP_E_INVALID otherwise,
+ * or when no feedback has been set since the last tick); WCQP_E_UNSUPPORTED on a handle with the internal plant.
+ * Replaces: WalkingController::setFeedback (:612), WalkingZMPController::setFeedback (:665), the joint part of
+ * WalkingQPIK::setRobotState (:373) of WM/src/WalkingModule.cpp. */
+int wcqp_tick_set_feedback_device(wcqp_tick_t h, const double* dcm_meas, const double* com_meas, const double* zmp_meas,
+                                  const double* q_meas, void* stream);
 int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out);             /* synchronises     */
 
 #ifdef __cplusplus

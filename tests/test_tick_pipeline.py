@@ -419,3 +419,73 @@ def test_tick_at_the_benchmark_geometry(wca, qs, kin_mode):
         ref = ts.run_ticks(ts.TickParams(), one, L, ipar, **({"kin_model": S.icub_like_model(), "foot_rect": S.FOOT_RECT} if kin_mode else {}))
         assert np.abs(full["u0_log"][:, i] - ref["u0_log"][:, 0]).max() <= 1e-9, i
         assert np.abs(full["dq_log"][:, i] - ref["dq_log"][:, 0]).max() <= 1e-8, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kin_mode", [False, True], ids=["constant_jacobians", "fused_kinematics"])
+def test_external_feedback_mode(wca, qs, kin_mode):
+    """wcqp_tick_params.plant = EXTERNAL: every tick reads the caller's measured DCM / CoM / ZMP (and joints) from
+    device arrays (wcqp_tick_set_feedback_device) instead of stepping the internal LIPM plant - what the reference reads from the robot every
+    tick (WM/src/WalkingModule.cpp:612, 665, 373).  (a) Fed the internal plant's OWN states, tick by tick, the pipeline reproduces the
+    internal run (1e-9 against oracle/tick_spec.py, whose logs are what is fed back); (b) fed other measurements - a disturbed DCM, a ZMP
+    that is not the previous command, measured joints that differ from the desired ones - it follows tick_spec.run_ticks(external=...);
+    (c) the call contract: one tick per run call, each behind its own feedback."""
+    import torch
+    from oracle import tick_spec as ts
+    B, T = 10, 60
+    p = ts.TickParams()
+    if kin_mode:
+        kin, d = _walk_scenario(wca, B, T)
+        vmax = wca.synth.WALK_VMAX.copy()
+        ipar = qs.IKParams(v_max=vmax, joint_reg_deg=wca.synth.WALK_POSTURE_DEG.copy())
+        okw = dict(kin_model=wca.synth.icub_like_model(), foot_rect=wca.synth.FOOT_RECT)
+        mk_ik = lambda: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=vmax, joint_reg_rad=np.deg2rad(wca.synth.WALK_POSTURE_DEG))
+    else:
+        kin, d = None, wca.synth.synth_tick_batch(B, T)
+        vmax = 0.45 * np.ones(23)
+        ipar, okw = qs.IKParams(v_max=vmax), {}
+        mk_ik = lambda: wca.IkSolver(form=wca.IK_FORM_QPOASES, v_max=0.45)
+    internal = ts.run_ticks(p, d, T, ipar, **okw)
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def run_external(ext):
+        pipe = wca.TickPipeline(B, T, wca.MpcSolver(), mk_ik(), log_ticks=T, kin=kin, external_feedback=True)
+        pipe.upload(d)
+        with pytest.raises(wca.WcqpError):
+            pipe.run(1)                                   # no feedback yet
+        for t in range(T):
+            fb = [up(ext[k][t]) for k in ("dcm", "com", "zmp")]
+            q = up(ext["q"][t]) if ext.get("q") is not None else None
+            pipe.set_feedback_device(fb[0].data_ptr(), fb[1].data_ptr(), fb[2].data_ptr(), q.data_ptr() if q is not None else 0)
+            if t == 3:
+                with pytest.raises(wca.WcqpError):
+                    pipe.run(2)                           # one tick per call
+            pipe.run(1)
+            torch.cuda.synchronize()                      # (the feedback tensors of this tick go out of scope next)
+        with pytest.raises(wca.WcqpError):
+            pipe.run(1)                                   # the feedback of tick T - 1 was consumed
+        return pipe.download()
+    # (a) the internal plant's own states fed back
+    same = run_external(dict(dcm=internal["dcm_log"], com=internal["com_log"], zmp=internal["zmp_log"]))
+    assert same["tick"] == T and np.array_equal(same["ik_fail"], internal["ik_fail"]) and same["mpc_fail"].sum() == 0
+    assert np.abs(same["u0_log"] - internal["u0_log"]).max() <= 1e-9 and np.abs(same["dq_log"] - internal["dq_log"]).max() <= 1e-8
+    assert np.abs(same["q_des"] - internal["q_des"]).max() <= 1e-9
+    # ... which is also what the pipeline with the INTERNAL plant does, whatever the launch form
+    pipe = wca.TickPipeline(B, T, wca.MpcSolver(), mk_ik(), log_ticks=T, kin=kin)
+    pipe.upload(d); pipe.run(T)
+    own = pipe.download()
+    assert np.abs(same["u0_log"] - own["u0_log"]).max() <= 1e-9 and np.abs(same["dq_log"] - own["dq_log"]).max() <= 1e-8
+    # (b) measurements of somebody else's plant
+    rng = np.random.default_rng(4)
+    ext = dict(dcm=internal["dcm_log"] + 1e-3 * rng.normal(size=(T, B, 2)), com=internal["com_log"] + 5e-4 * rng.normal(size=(T, B, 2)),
+               zmp=internal["zmp_log"] + 2e-3 * rng.normal(size=(T, B, 2)), q=internal["q_log"] + 0.01 * rng.normal(size=(T, B, 23)))
+    ref = ts.run_ticks(p, d, T, ipar, external=ext, **okw)
+    out = run_external(ext)
+    assert np.array_equal(out["ik_fail"], ref["ik_fail"]) and np.array_equal(out["mpc_fail"], ref["mpc_fail"])
+    assert np.abs(out["u0_log"] - ref["u0_log"]).max() <= 1e-9 and np.abs(out["dq_log"] - ref["dq_log"]).max() <= 1e-8
+    assert np.abs(out["q_des"] - ref["q_des"]).max() <= 1e-9
+    assert np.abs(ref["u0_log"] - internal["u0_log"]).max() > 1e-4 and np.abs(ref["dq_log"] - internal["dq_log"]).max() > 1e-3      # it really is another run
+    # the internal-plant handle refuses feedback
+    with pytest.raises(wca.WcqpError):
+        pipe.set_feedback_device(1, 1, 1)

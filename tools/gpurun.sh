@@ -32,6 +32,14 @@ suite)          # the GPU suite, smoke, the driver's bench command
     timeout -k 10 500 python bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err || fail bench $O/bench_driver.err
     last_json $O/bench_driver.json
     ;;
+bench)          # new bench-related tests, the driver's command, a 2-rank gloo rehearsal
+    timeout -k 10 900 python -m pytest tests/test_bench_line.py tests/test_sharding_gloo.py tests/test_robots.py -m gpu -q -x > $O/pytest.log 2>&1 || fail pytest $O/pytest.log
+    tail -1 $O/pytest.log
+    timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err || fail bench $O/bench_driver.err
+    last_json $O/bench_driver.json
+    WCQP_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 20 --warmup 5 --tick-ticks 200 > $O/bench_gpus2_gloo_rehearsal.json 2> $O/g2.err || fail "bench gpus 2" $O/g2.err
+    last_json $O/bench_gpus2_gloo_rehearsal.json
+    ;;
 split)          # one combined plan against IK-only + MPC-only plans enqueued together, for the libraries given (product = "")
     for lib in "$@"; do
         tag=${lib:-product}

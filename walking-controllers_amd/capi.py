@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "wcqp_hull_from_feet_device", "wcqp_hull_from_feet_host",
     "wcqp_kin_create", "wcqp_kin_destroy", "wcqp_kin_jacobians_device", "wcqp_kin_jacobians_host",
     "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download", "wcqp_tick_splice_reference",
+    "wcqp_tick_set_feedback_device",
     "wcqp_qp_enqueue_steps", "wcqp_qp_plan_create", "wcqp_qp_plan_enqueue", "wcqp_qp_plan_destroy",
     "wcqp_slab_layout_for", "wcqp_qp_step_from_slabs",
 )
@@ -164,7 +165,7 @@ class TickParams(C.Structure):
                 ("k_com", C.c_double), ("k_zmp", C.c_double), ("noise", C.c_double), ("seed", C.c_uint64),
                 ("mpc", MpcParams), ("ik", IkParams),
                 ("ik_cold_start_only", C.c_int32), ("use_kinematics", C.c_int32), ("kin", KinParams), ("foot_rect", C.c_double * 8),
-                ("kin_handoff", C.c_int32), ("ticks_per_launch", C.c_int32), ("logger_ticks", C.c_int32)]
+                ("kin_handoff", C.c_int32), ("ticks_per_launch", C.c_int32), ("logger_ticks", C.c_int32), ("plant", C.c_int32)]
 
 
 class TickInputs(C.Structure):
@@ -218,6 +219,7 @@ def lib() -> C.CDLL:
         L.wcqp_tick_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.wcqp_tick_download.argtypes = [C.c_void_p, C.POINTER(TickOutputs)]
         L.wcqp_tick_splice_reference.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.wcqp_tick_set_feedback_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wcqp_qp_enqueue_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.POINTER(C.c_int32)]
         L.wcqp_qp_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.c_int32, C.POINTER(C.c_void_p)]
         L.wcqp_qp_plan_enqueue.argtypes = [C.c_void_p, C.c_void_p]
@@ -436,7 +438,7 @@ class TickPipeline:
     def __init__(self, batch, max_ticks, mpc: MpcSolver, ik: IkSolver, first=0, log_ticks=0,
                  step_ticks=180, ds_ticks=110, k_com=9.0, k_zmp=3.0, noise=1e-4, seed=99,
                  kin: "Optional[KinModel]" = None, foot_rect=None, ik_hot_start: bool = True, kin_handoff: int = 0,
-                 ticks_per_launch: int = 0, logger_ticks: int = 0):
+                 ticks_per_launch: int = 0, logger_ticks: int = 0, external_feedback: bool = False):
         """kin: a KinModel -> per-tick kinematics (Jacobians, actual poses and hull rows rebuilt every tick from the
         integrated joint state with the base anchored at the stance foot; upload() then ignores J_* / hull_tab_*)."""
         self.batch, self.max_ticks, self.log_ticks, self.dof = batch, max_ticks, log_ticks, ik.dof
@@ -447,7 +449,8 @@ class TickPipeline:
             foot_rect = FOOT_RECT
         self.params = TickParams(batch, first, max_ticks, log_ticks, step_ticks, ds_ticks, k_com, k_zmp, noise, seed,
                                  mpc.params, ik.params, int(not ik_hot_start), int(self.use_kin), kin.params if kin is not None else KinParams(),
-                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(kin_handoff), int(ticks_per_launch), int(logger_ticks))
+                                 (C.c_double * 8)(*np.asarray(foot_rect, float).reshape(8)), int(kin_handoff), int(ticks_per_launch), int(logger_ticks),
+                                 int(bool(external_feedback)))
         self._h = C.c_void_p()
         check(lib().wcqp_tick_create(C.byref(self.params), C.byref(self._h)), "wcqp_tick_create")
         self._keep = None
@@ -476,6 +479,11 @@ class TickPipeline:
 
     def run(self, n_ticks: int, use_graph: bool = True, stream: int = 0):
         check(lib().wcqp_tick_run(self._h, int(n_ticks), int(bool(use_graph)), stream or None), "wcqp_tick_run")
+
+    def set_feedback_device(self, dcm_meas: int, com_meas: int, zmp_meas: int, q_meas: int = 0, stream: int = 0):
+        """External feedback (plant = EXTERNAL): raw DEVICE addresses of the measured DCM / CoM / ZMP [B][2] and, optionally, joint positions
+        [B][dof] the next tick is to use; enqueue only."""
+        check(lib().wcqp_tick_set_feedback_device(self._h, dcm_meas, com_meas, zmp_meas, q_meas or None, stream or None), "wcqp_tick_set_feedback_device")
 
     def splice_reference(self, from_tick: int, ref_tail, stream: int = 0):
         """Trajectory merge: stages [from_tick, from_tick + n) of every instance's DCM reference <- ref_tail[B][n][2]."""

@@ -142,7 +142,10 @@ struct MpcPairArgs {
 // kinematics kernel (tick_device.h), 2 the kinematics phase of this kernel itself (no hand-off through memory at all)
 // LOG (tick kernel, wcqp_tick_params.logger_ticks > 0): also writes the reference's logger row of every robot-tick; a kernel
 // of its own, so that the product kernels carry none of it
-template <bool TICK, int JSRC = 0, bool PAIR = false, bool LOG = false>
+// EXT (tick kernel, wcqp_tick_params.plant = EXTERNAL): the IK regularises towards the caller's MEASURED joint positions
+// (TickDev::q_meas) instead of the desired ones - a kernel of its own: the two registers it holds across the kinematics phase
+// cost the fused-kinematics kernel 28 B of scratch, which the product kernel does not pay
+template <bool TICK, int JSRC = 0, bool PAIR = false, bool LOG = false, bool EXT = false>
 __device__ __forceinline__
 void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -197,6 +200,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     if constexpr (!KINF) load_lane_constants();
     double a0[NROWS_IN], a1[NROWS_IN];     // columns of [J_left; J_right; J_com; J_neck]
     double q0, q1;
+    double qm0, qm1;                       // the joint positions the IK's regularisation sees (tick with external feedback: measured ones)
     bool osqp_form;
     double k_pos_foot, k_att_foot, k_pos_com, kap;
     int fast_ok;
@@ -239,6 +243,10 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             q0 = qpos[inst * kDof + j];
             q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
         }
+        auto load_measured_joints = [&]() {
+            if constexpr (EXT) { const double* qm = td.q_meas; qm0 = qm[inst * kDof + j]; qm1 = qm[inst * kDof + (var1 ? col1 : 0)]; }
+        };
+        if constexpr (TICK && !KINF) load_measured_joints();
         double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0, g_ok = 1.0, g_sw = 0.0, g_h0 = 0.0;
         auto load_handoff = [&]() {
             // hand-off of MPC(t): desired CoM position / velocity (WalkingModule.cpp:686-695), the plant's CoM, did the MPC end usable
@@ -502,6 +510,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             load_lane_constants();
             load_handoff();
             load_previous_set();
+            load_measured_joints();
             wcqp::wave_lds_fence();              // everything of the kinematics scratch has been read
             if (j >= 11 && j < 14) {
                 // B_R - B_L, B_C - B_L for the row operations, column cm: B_f = -S(p_f - p_base), column cm = e_cm x (p_f - p_base) -
@@ -702,9 +711,11 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         // neck target e = kappa (-k_neck) e_R(R_neck, R_neck,d)   (osqp.cpp:181-196, qp.cpp:161-178)
         if (j >= 13) bv[15 + (j - 13)] = kap * rot_err(st + 48, st + 57, j - 13);
     }
-    // gradient of the joint regularisation in the scaled variable: g~ = Lam^-1/2 (-w K (q_reg - q))
-    const double gt0 = -sd0 * kq0 * (qreg0 - q0);
-    const double gt1 = var1 ? -sd1 * kq1 * (qreg1 - q1) : 0.0;
+    // gradient of the joint regularisation in the scaled variable: g~ = Lam^-1/2 (-w K (q_reg - q)); q = the MEASURED joint positions
+    // (setRobotState, WalkingModule.cpp:373) - the desired ones unless the tick runs on external feedback
+    if constexpr (!EXT) { qm0 = q0; qm1 = q1; }
+    const double gt0 = -sd0 * kq0 * (qreg0 - qm0);
+    const double gt1 = var1 ? -sd1 * kq1 * (qreg1 - qm1) : 0.0;
     wcqp::wave_lds_fence();
     if (rhs1) {
         const double* bv = S + OFF_BV;
@@ -1535,7 +1546,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 // memory for tick t + 1 (joint state, hand-off record, previous active set, live hull rows) is written and read by the
 // same wave, ordered by a workgroup-scope fence per tick.  No per-tick launch, no ramp-up / tail per tick, and a wave
 // whose robots walk a long active set on one tick catches up on the next instead of holding the whole launch.
-template <bool TICK, int JSRC, bool LOG = false>
+template <bool TICK, int JSRC, bool LOG = false, bool EXT = false>
 __global__ __launch_bounds__(64, WCQP_IK4_WAVES)
 void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* __restrict__ JL, const double* __restrict__ JR,
@@ -1576,7 +1587,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll 1
         for (int k = 0; k < n_inner; ++k) {
             __asm__ volatile("" ::: "memory");        // nothing of the body is hoisted out of the loop (its registers are all spoken for)
-            ik4_body<TICK, JSRC, false, LOG>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
+            ik4_body<TICK, JSRC, false, LOG, EXT>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, td, smem,
                                              (int)blockIdx.x, t0 + k, !(skip_last_mpc && k == n_inner - 1), kmodel, kgains, nullptr, carry, &gait, &nbase);
             gait = gait + 1 == 2 * td.step_ticks ? 0 : gait + 1;
             // tick t + 1 of this wave reads what tick t wrote (other lanes of the same wave): visible before it starts
@@ -1593,6 +1604,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
 
 // The MPC chain of ONE tick for every robot, on its own: primes the skewed tick after an upload (MPC(0) has to have run
 // before the first fused launch, which carries IK(0) and MPC(1)).
+template <bool EXT>
 __global__ __launch_bounds__(64)
 void tick_mpc_prime_kernel(wcqp_tick::TickDev td, int t)
 {
@@ -1603,7 +1615,7 @@ void tick_mpc_prime_kernel(wcqp_tick::TickDev td, int t)
     const long inst = live ? inst_raw : (long)td.batch - 1;
     wcqp_tick::TickMpcRegs mreg;
     wcqp_tick::tick_mpc_issue(td, j, inst, t, mreg);
-    wcqp_tick::tick_mpc_finish(td, j, inst, live, t, mreg, s_hull[grp]);
+    wcqp_tick::tick_mpc_finish<false, EXT>(td, j, inst, live, t, mreg, s_hull[grp]);
 }
 
 // Both QPs of a batch of robot-ticks in ONE launch (wcqp_qp_enqueue_steps, a record whose two calls go to the same
@@ -1813,6 +1825,18 @@ int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_
         WCQP_HIP_TRY(hipGetLastError());
         return WCQP_OK;
     }
+    if (td.q_meas) {
+        // external feedback (wcqp_tick_params.plant = EXTERNAL): measured joints in the IK's regularisation; one tick per launch
+        if (n_inner != 1 || td.compact) return WCQP_E_INVALID;
+        if (td.kin_fused)
+            hipLaunchKernelGGL((ik4_kernel<true, 2, false, true>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
+                               JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
+        else
+            hipLaunchKernelGGL((ik4_kernel<true, 0, false, true>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
+                               JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
+        WCQP_HIP_TRY(hipGetLastError());
+        return WCQP_OK;
+    }
     if (td.kin_fused)
         hipLaunchKernelGGL((ik4_kernel<true, 2>), dim3(grid), dim3(64), 0, stream, prm, td.batch,
                            JL, JR, JN, JC, td.q_des, td.state, td.dq, td.ik_status, alo, aup, nullptr, nullptr, td_dev, td.phase, n_inner, skip_last_mpc);
@@ -1830,7 +1854,8 @@ int ik4_launch_tick(const void* d_prm, const wcqp_tick::TickDev& td, const wcqp_
 int ik4_launch_tick_prime(const wcqp_tick::TickDev& td, int t, hipStream_t stream) {
     if (!td.skew || !td.mst || !td.hand) return WCQP_E_INVALID;
     const unsigned grid = (unsigned)((td.batch + 3) / 4);
-    hipLaunchKernelGGL(tick_mpc_prime_kernel, dim3(grid), dim3(64), 0, stream, td, t);
+    if (td.q_meas) hipLaunchKernelGGL(tick_mpc_prime_kernel<true>, dim3(grid), dim3(64), 0, stream, td, t);      // external feedback: the caller's measured ZMP
+    else hipLaunchKernelGGL(tick_mpc_prime_kernel<false>, dim3(grid), dim3(64), 0, stream, td, t);
     WCQP_HIP_TRY(hipGetLastError());
     return WCQP_OK;
 }

@@ -50,6 +50,20 @@ __global__ void tick_post_kernel(TickDev d) {
     if (g == 0) d.tick2[1 - d.phase] = t + 1;      // advanceReferenceSignals (WalkingModule.cpp:816)
 }
 
+// external feedback: the caller's measured state into the places the next tick reads its plant state from - the skewed
+// chain's per-axis records (mst: com [2], dcm [6], measured ZMP [7]) - and the measured joints into q_meas (NULL: the desired ones)
+__global__ void tick_feedback_kernel(TickDev d, const double* __restrict__ dcm, const double* __restrict__ com, const double* __restrict__ zmp,
+                                     const double* __restrict__ q, double* __restrict__ q_meas) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.batch * kDof) return;
+    const int i = g / kDof, jj = g % kDof;
+    q_meas[g] = q ? q[g] : d.q_des[g];
+    if (jj < 2) {
+        double* r = d.mst + ((size_t)i * 2 + jj) * 8;
+        r[2] = com[2 * i + jj]; r[6] = dcm[2 * i + jj]; r[7] = zmp[2 * i + jj];
+    }
+}
+
 }  // namespace
 
 struct wcqp_tick_s {
@@ -79,6 +93,8 @@ struct wcqp_tick_s {
     double* splice_stage = nullptr; size_t splice_cap = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t splice_done = nullptr; bool splice_pending = false;
+    bool external = false, feedback_set = false;     // wcqp_tick_params.plant = EXTERNAL: one tick per run call, each behind a set_feedback
+    double* q_meas = nullptr;
 };
 
 namespace {
@@ -164,6 +180,8 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     // back WCQP_STATUS_STRUCTURE and counts as an IK failure
     h->d.hot_start = params->ik_cold_start_only ? 0 : 1;
     if (params->ticks_per_launch < 0 || params->logger_ticks < 0) { wcqp_tick_destroy(h); return WCQP_E_INVALID; }
+    if (params->plant != WCQP_TICK_PLANT_INTERNAL && params->plant != WCQP_TICK_PLANT_EXTERNAL) { wcqp_tick_destroy(h); return WCQP_E_INVALID; }
+    h->external = params->plant == WCQP_TICK_PLANT_EXTERNAL;
     h->base_elim = h->fused && params->ik.algorithm != WCQP_IK_ALG_NULLSPACE_16L &&
                    params->ik.jacobian_structure != WCQP_IK_JAC_GENERAL && wcqp::ik_fast_ok(h->ik);
     const size_t B = (size_t)params->batch;
@@ -205,6 +223,9 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     const bool fusedk = masks_ok && params->kin_handoff == WCQP_KIN_HANDOFF_FUSED && N < kGainsLdsStages &&
                         wcqp::kin_fused_tables(h->kin, ktab, &d.kin_rounds);
     const bool compact = masks_ok && !fusedk && params->kin_handoff != WCQP_KIN_HANDOFF_DENSE;
+    // external feedback: the default (base-eliminated) kernel with constant Jacobians or fused kinematics, without logger rows
+    if (h->external && (!d.skew || params->logger_ticks > 0 || (h->kin && !fusedk))) { wcqp_tick_destroy(h); return WCQP_E_UNSUPPORTED; }
+    if (h->external) { A_(h->q_meas, B * kDof); d.q_meas = h->q_meas; }
     if (d.skew) {
         A_(d.mst, B * 16); A_(d.hand, 2 * B * kHandLen); A_(d.live_A, B * 16); A_(d.live_b, B * 8); A_(d.live_nc, B); A_(d.sel_built, B);
         if (compact) A_(jcomp, B * (size_t)cstride);
@@ -224,6 +245,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     if (fusedk) { d.kin_fused = 1; d.cmaskL = cm[0]; d.cmaskR = cm[1]; d.cmaskN = cm[2]; }
     // several ticks per launch: whenever a tick is ONE launch of the fused kernel (no kinematics launch in between)
     h->ticks_per_launch = (d.skew && (!h->kin || fusedk)) ? (params->ticks_per_launch > 0 ? params->ticks_per_launch : (1 << 20)) : 1;
+    if (h->external) h->ticks_per_launch = 1;            // a tick cannot run ahead of its feedback
     if (h->kin) {
         double* h0 = nullptr;
         if (dev_alloc(h, &h0, B) != WCQP_OK) { wcqp_tick_destroy(h); return WCQP_E_NOMEM; }
@@ -276,7 +298,7 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
             for (int ax = 0; ax < 2; ++ax) {
                 double* r = &mst[(i * 2 + ax) * 8];
                 r[0] = in->com0[2 * i + ax]; r[2] = in->com0[2 * i + ax]; r[3] = in->u_init[2 * i + ax];
-                r[4] = in->com0[2 * i + ax]; r[6] = in->dcm0[2 * i + ax];
+                r[4] = in->com0[2 * i + ax]; r[6] = in->dcm0[2 * i + ax]; r[7] = in->u_init[2 * i + ax];
             }
         WCQP_HIP_TRY(hipMemcpy(d.mst, mst.data(), B * 16 * 8, hipMemcpyHostToDevice));
         WCQP_HIP_TRY(hipMemset(d.sel_built, 0xff, B * 4));           // -1: every robot builds / copies its live rows at tick 0
@@ -319,6 +341,18 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     h->uploaded = true;
     h->ticks_enqueued = 0;
     h->phase = 0;
+    h->feedback_set = false;
+    return WCQP_OK;
+}
+
+int wcqp_tick_set_feedback_device(wcqp_tick_t h, const double* dcm_meas, const double* com_meas, const double* zmp_meas, const double* q_meas, void* stream) {
+    if (!h || !dcm_meas || !com_meas || !zmp_meas) return WCQP_E_INVALID;
+    if (!h->external) return WCQP_E_UNSUPPORTED;
+    if (!h->uploaded) return WCQP_E_INVALID;
+    const int n = h->d.batch * kDof;
+    hipLaunchKernelGGL(tick_feedback_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d, dcm_meas, com_meas, zmp_meas, q_meas, h->q_meas);
+    WCQP_HIP_TRY(hipGetLastError());
+    h->feedback_set = true;
     return WCQP_OK;
 }
 
@@ -328,6 +362,7 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
     if ((long)h->ticks_enqueued + n_ticks > (long)h->p.max_ticks) return WCQP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (n_ticks == 0) return WCQP_OK;
+    if (h->external && (n_ticks != 1 || !h->feedback_set)) return WCQP_E_INVALID;      // one tick per call, each behind its own feedback
     int left = n_ticks;
     // Everything that can be refused on the host is refused BEFORE anything is enqueued (the prime launch below already advances
     // the MPC chain); an enqueue that fails after that leaves device state nobody can name - the handle then wants a new upload.
@@ -387,6 +422,7 @@ int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* strea
         h->phase ^= 1; ++h->ticks_enqueued;
     }
     guard.armed = false;
+    h->feedback_set = false;
     return WCQP_OK;
 }
 

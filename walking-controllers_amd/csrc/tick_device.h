@@ -48,8 +48,9 @@ struct TickDev {
     // The MPC chain MPC(t) -> ZMP-CoM law -> LIPM plant -> MPC(t+1) does not depend on the IK, so the MPC of the NEXT tick
     // runs in the shadow of this tick's Jacobian loads; its outputs reach IK(t+1) through a hand-off record.
     int skew;
-    wcqp::GPtr<double> mst;        // [B][2][8] state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (= measured ZMP), p_star,
-                        //           v_star_prev, dcm, spare - one 64-byte record per axis, loaded as four 16-byte pieces
+    wcqp::GPtr<double> mst;        // [B][2][8] state of the MPC chain per axis: c_ref, v_ref_prev, com, u_prev (the previous command), p_star,
+                        //           v_star_prev, dcm, measured ZMP (the internal plant: = the previous command; external feedback:
+                        //           the caller's) - one 64-byte record per axis, loaded as four 16-byte pieces
     wcqp::GPtr<double> hand;       // [2][B][kHandLen] MPC(t) -> IK(t) at parity t & 1: p_star xy, v_star xy, com(t) xy, dcm(t) xy, mpc_ok, spare,
                         //           measured ZMP(t) xy (= the previous command), u0(t) xy   (com / dcm / ZMP: the plant at the START of
                         //           tick t; the last six entries feed the logger rows only)
@@ -76,6 +77,10 @@ struct TickDev {
     double inv_ss;      // 1 / (step_ticks - ds_ticks): the swing phase of a tick as a product (the tick kernel carries the gait cycle index
                         // of its robots from tick to tick instead of dividing its way to it: ik4.hip)
     wcqp::GPtr<unsigned long long> stamps;     // diagnostic builds (-DWCQP_TICK_STAMPS): [workgroups][16] s_memtime at the phase boundaries; else NULL
+    // ---- external feedback (wcqp_tick_params.plant = EXTERNAL): the MEASURED joint positions the IK regularises towards
+    // (WalkingModule.cpp:373: setRobotState gets the measured joints while the kinematics run at the desired ones, Appendix B-18);
+    // NULL with the internal plant (measured = desired).  Measured DCM / CoM / ZMP go straight into the chain's state records.
+    wcqp::GPtr<const double> q_meas;           // [B][dof], written by wcqp_tick_set_feedback_device
 };
 constexpr int kHandLen = 14;
 constexpr int kLoggerCols = 53;
@@ -251,6 +256,9 @@ __device__ __forceinline__ void tick_mpc_partial(const TickDev& d, int j, long i
         wcqp_mpc::mpc_row_extra_passes(d.mpc, j, reinterpret_cast<const double2*>(d.ref_traj.get()) + inst * d.traj_len + t, d.horizon + 1, ux, uy);
 }
 // r0: stage 0 of the window (the reference DCM of tick t; meaningful on lane 0)
+// EXT (external feedback: only tick_mpc_prime_kernel<true> - with such a handle every tick's MPC runs there): the measured ZMP is the
+// caller's (record entry 7), not the previous command; the kernels of the internal plant keep entry 7 out of their registers
+template <bool EXT = false>
 __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double2 r0, double ux, double uy,
                                                      double (*s_hull)[4], int code_known = -1, const unsigned long long* noise_base = nullptr) {
     // contact pair of tick t; the live row set follows it (WalkingController::setConvexHullConstraint switches rows only
@@ -297,34 +305,36 @@ __device__ __forceinline__ void tick_mpc_finish_from(const TickDev& d, int j, lo
         const int ax = j;
         const double c_ref0 = R.s01.x, v_ref_prev = R.s01.y, com = R.s23.x, u_prev = R.s23.y;
         const double p_star0 = R.s45.x, v_star_prev = R.s45.y, xi = R.s67.x;
+        const double zmp_meas = EXT ? R.s67.y : u_prev;
         // StableDCMModel::integrateModel (StableDCMModel.cpp:63-90), Tustin integrator
         const double rr = ax == 0 ? r0.x : r_y;        // reference DCM of tick t: stage 0 of the window (lane 0 holds it)
         const double vr = -d.omega * (c_ref0 - rr);
         const double c_ref = c_ref0 + 0.5 * d.dT * (vr + v_ref_prev);
         const double u = mpc_ok ? (ax == 0 ? u0x : u0y) : u_prev;        // hold the last command on failure
-        // WalkingZMPController::evaluateControl (WalkingZMPController.cpp:146-173); the measured ZMP is the previous command
-        const double v = d.k_com * (c_ref - com) - d.k_zmp * (u - u_prev) + vr;
+        // WalkingZMPController::evaluateControl (WalkingZMPController.cpp:146-173); the measured ZMP: with the internal plant the
+        // previous command (the same number as u_prev), with external feedback what the caller measured
+        const double v = d.k_com * (c_ref - com) - d.k_zmp * (u - zmp_meas) + vr;
         const double p_star = p_star0 + 0.5 * d.dT * (v + v_star_prev);
         // synthetic plant: LIPM with a bounded disturbance
         const double com1 = com + d.dT * (-d.omega * (com - xi));
         const double w_ = noise_base ? disturbance_from(*noise_base, t, ax) : disturbance(d.seed, (unsigned long long)(d.first + inst), t, ax);
         const double xi1 = d.a * xi + d.b * u + d.noise * w_;
         double2* sp = reinterpret_cast<double2*>(d.mst.get() + (inst * 2 + ax) * 8);
-        sp[0] = make_double2(c_ref, vr); sp[1] = make_double2(com1, u); sp[2] = make_double2(p_star, v); sp[3] = make_double2(xi1, 0.0);
+        sp[0] = make_double2(c_ref, vr); sp[1] = make_double2(com1, u); sp[2] = make_double2(p_star, v); sp[3] = make_double2(xi1, EXT ? u : 0.0);
         // hand-off to the IK of tick t (desired CoM position / velocity, WalkingModule.cpp:686-695) + the plant state at the start of tick t
         double* hd = d.hand + ((size_t)(t & 1) * d.batch + inst) * kHandLen;
         hd[ax] = p_star; hd[2 + ax] = v; hd[4 + ax] = com; hd[6 + ax] = xi;
         if (ax == 0) hd[8] = mpc_ok ? 1.0 : 0.0;
-        hd[10 + ax] = u_prev; hd[12 + ax] = u;
+        hd[10 + ax] = zmp_meas; hd[12 + ax] = u;
         if (t < d.log_ticks) d.u0_log[((size_t)t * d.batch + inst) * 2 + ax] = u;
     }
 }
-template <bool GAINS_LDS = false>
+template <bool GAINS_LDS = false, bool EXT = false>
 __device__ __forceinline__ void tick_mpc_finish(const TickDev& d, int j, long inst, bool live, int t, TickMpcRegs& R, double (*s_hull)[4],
                                                 const double* gr_lds = nullptr, int code_known = -1, const unsigned long long* noise_base = nullptr) {
     double ux, uy;
     tick_mpc_partial<GAINS_LDS>(d, j, inst, t, R, gr_lds, ux, uy);
-    tick_mpc_finish_from(d, j, inst, live, t, R, R.L.r[0], ux, uy, s_hull, code_known, noise_base);
+    tick_mpc_finish_from<EXT>(d, j, inst, live, t, R, R.L.r[0], ux, uy, s_hull, code_known, noise_base);
 }
 // the same two with the gait cycle index cyc = (t + phase0) % (2 step_ticks) at hand (the tick kernel carries it from tick to tick:
 // integer divisions by run-time values are ~35 instructions each, and a tick had four of them, on every lane)
