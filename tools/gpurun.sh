@@ -40,6 +40,44 @@ bench)          # new bench-related tests, the driver's command, a 2-rank gloo r
     WCQP_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 20 --warmup 5 --tick-ticks 200 > $O/bench_gpus2_gloo_rehearsal.json 2> $O/g2.err || fail "bench gpus 2" $O/g2.err
     last_json $O/bench_gpus2_gloo_rehearsal.json
     ;;
+diet)           # after a kernel edit: the GPU suite, the two bench forms, and the dynamic instruction mix of the plan / fused-tick kernels (PMC)
+    tag=${1:-cur}
+    timeout -k 10 1100 python -m pytest tests -m gpu -q -x > $O/pytest_$tag.log 2>&1 || fail pytest $O/pytest_$tag.log
+    tail -1 $O/pytest_$tag.log
+    timeout -k 10 400 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-tick > $O/bench200_$tag.json 2> $O/bench200_$tag.err || fail bench200 $O/bench200_$tag.err
+    timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench20_$tag.json 2> $O/bench20_$tag.err || fail bench20 $O/bench20_$tag.err
+    last_json $O/bench200_$tag.json $O/bench20_$tag.json
+    R0=$PWD; cd /tmp && export TMPDIR=/tmp
+    P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU"
+    P2="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_MFMA"
+    n=1
+    for P in "$P1" "$P2"; do
+        timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R0/$O/pmc_$tag/plan_4096_p$n -- python3 $R0/bench.py --steps 88 --warmup 88 --repeats 1 --batch 4096 --no-cpu-baseline --no-tick > $R0/$O/pmc_plan_p$n.log 2>&1 < /dev/null || fail "pmc plan $n" $R0/$O/pmc_plan_p$n.log
+        timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R0/$O/pmc_$tag/tickkin_8192_p$n -- python3 $R0/bench.py --workload tick --batch 8192 --steps 200 --warmup 24 --no-cpu-baseline > $R0/$O/pmc_tickkin_p$n.log 2>&1 < /dev/null || fail "pmc tick $n" $R0/$O/pmc_tickkin_p$n.log
+        n=$((n+1))
+    done
+    cd $R0
+    python3 tools/pmc/summarize.py $O/pmc_$tag > $O/pmc_summary_$tag.json 2> $O/pmc_summary_$tag.err
+    rm -rf $O/pmc_$tag
+    python3 - $O/pmc_summary_$tag.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+def digest(prefix, kern, units):
+    c = {}
+    for p in ("p1", "p2"):
+        for k, v in d.get("%s_%s" % (prefix, p), {}).get(kern, {}).items():
+            c[k] = v["total"]
+    if not c: return None
+    g = lambda k: c.get(k, 0.0)
+    return {"valu": g("SQ_INSTS_VALU") / units, "lds": g("SQ_INSTS_LDS") / units, "salu": g("SQ_INSTS_SALU") / units, "vmem_rd": g("SQ_INSTS_VMEM_RD") / units, "smem": g("SQ_INSTS_SMEM") / units,
+            "mfma": g("SQ_INSTS_MFMA") / units, "wave_cycles": 4 * g("SQ_WAVE_CYCLES") / units, "valu_issue_share": g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1),
+            "any_issue_share": g("SQ_ACTIVE_INST_ANY") / max(g("SQ_WAVE_CYCLES"), 1), "lds_conflict_share": g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1)}
+# bench.py --steps 88 --warmup 88 --repeats 1: the warm-up plan, the timed plan and the roofline pass's 4 launches, 88 records x 1024 robot groups each
+launches = d.get("plan_4096_p1", {}).get("qp_plan_kernel", {}).get("SQ_WAVES", {}).get("launches", 0)
+print("qp_plan_kernel per wave-record:", json.dumps(digest("plan_4096", "qp_plan_kernel", max(1, launches) * 88 * 1024)))
+print("ik4 fused tick per wave-tick:", json.dumps(digest("tickkin_8192", "ik4_tick_kernel", 224 * 2048)))
+PY
+    ;;
 split)          # one combined plan against IK-only + MPC-only plans enqueued together, for the libraries given (product = "")
     for lib in "$@"; do
         tag=${lib:-product}

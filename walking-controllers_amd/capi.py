@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "wcqp_hull_from_feet_device", "wcqp_hull_from_feet_host",
     "wcqp_kin_create", "wcqp_kin_destroy", "wcqp_kin_jacobians_device", "wcqp_kin_jacobians_host",
     "wcqp_tick_create", "wcqp_tick_destroy", "wcqp_tick_upload", "wcqp_tick_run", "wcqp_tick_download", "wcqp_tick_splice_reference",
-    "wcqp_tick_set_feedback_device",
+    "wcqp_tick_set_feedback_device", "wcqp_tick_set_feedback_host",
     "wcqp_qp_enqueue_steps", "wcqp_qp_plan_create", "wcqp_qp_plan_enqueue", "wcqp_qp_plan_destroy",
     "wcqp_slab_layout_for", "wcqp_qp_step_from_slabs",
 )
@@ -220,6 +220,7 @@ def lib() -> C.CDLL:
         L.wcqp_tick_download.argtypes = [C.c_void_p, C.POINTER(TickOutputs)]
         L.wcqp_tick_splice_reference.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.wcqp_tick_set_feedback_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wcqp_tick_set_feedback_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wcqp_qp_enqueue_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.POINTER(C.c_int32)]
         L.wcqp_qp_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(QpStep), C.c_int32, C.POINTER(C.c_void_p)]
         L.wcqp_qp_plan_enqueue.argtypes = [C.c_void_p, C.c_void_p]
@@ -484,6 +485,13 @@ class TickPipeline:
         """External feedback (plant = EXTERNAL): raw DEVICE addresses of the measured DCM / CoM / ZMP [B][2] and, optionally, joint positions
         [B][dof] the next tick is to use; enqueue only."""
         check(lib().wcqp_tick_set_feedback_device(self._h, dcm_meas, com_meas, zmp_meas, q_meas or None, stream or None), "wcqp_tick_set_feedback_device")
+
+    def set_feedback_host(self, dcm_meas, com_meas, zmp_meas, q_meas=None):
+        """External feedback from host arrays ([B][2] each, q_meas [B][dof] or None): staged and enqueued on the NULL stream."""
+        a = [_f64(x) for x in (dcm_meas, com_meas, zmp_meas)]
+        q = None if q_meas is None else _f64(q_meas)
+        assert all(x.shape == (self.batch, 2) for x in a) and (q is None or q.shape == (self.batch, self.dof))
+        check(lib().wcqp_tick_set_feedback_host(self._h, _p(a[0]), _p(a[1]), _p(a[2]), _p(q)), "wcqp_tick_set_feedback_host")
 
     def splice_reference(self, from_tick: int, ref_tail, stream: int = 0):
         """Trajectory merge: stages [from_tick, from_tick + n) of every instance's DCM reference <- ref_tail[B][n][2]."""

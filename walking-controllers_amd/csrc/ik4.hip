@@ -170,6 +170,10 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     const long inst_raw = (long)blk * 4 + grp;
     const bool live = inst_raw < batch;
     const long inst = live ? inst_raw : (long)batch - 1;
+    // 32-bit addressing (wcqp::at32): uniform array base + this lane's BYTE offset - the host entry points refuse batches whose
+    // arrays do not fit 4 GB
+    using wcqp::at32;
+    const unsigned iu = (unsigned)inst, j8 = (unsigned)j * 8u;
     double* S = smem[grp];
     double* st = S + OFF_ST;
     const double inf = std::numeric_limits<double>::infinity();
@@ -181,7 +185,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     unsigned prev_lo = 0u, prev_up = 0u;            // hot start: the previous tick's active bounds of this instance
     bool stopped = false;                           // tick pipeline: the robot's IK failed on an earlier tick (tick_device.h)
     auto load_previous_set = [&]() {
-        if (td.hot_start && alo_out && aup_out) { prev_lo = alo_out[inst]; prev_up = aup_out[inst]; }
+        if (td.hot_start && alo_out && aup_out) { prev_lo = *at32(alo_out, iu * 4u); prev_up = *at32(aup_out, iu * 4u); }
         stopped = wcqp_tick::tick_robot_stopped(td, (int)inst);
         if (stopped) { prev_lo = 0u; prev_up = 0u; }
     };
@@ -212,12 +216,14 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     double2 p_xs = make_double2(0.0, 0.0), p_up = make_double2(0.0, 0.0);
     if constexpr (PAIR) {
         if (pm->has_mpc) {          // (an IK-only plan has no MPC part: a compile-time constant in either plan kernel)
-        const double2* rp = reinterpret_cast<const double2*>(pm->ref) + inst * pm->ref_len;
-        wcqp_mpc::mpc_window_loads(pm->c, j, rp, pm->ref_len, mreg.L);
-        if (j == 0) { p_xs = reinterpret_cast<const double2*>(pm->x0)[inst]; p_up = reinterpret_cast<const double2*>(pm->u_prev)[inst]; }
-        mreg.nc = pm->hull_nc[inst];
+        wcqp_mpc::mpc_window_loads(pm->c, j, reinterpret_cast<const double2*>(pm->ref), iu * (unsigned)pm->ref_len, pm->ref_len, mreg.L);
+        if (j == 0) { p_xs = *at32(reinterpret_cast<const double2*>(pm->x0), iu * 16u); p_up = *at32(reinterpret_cast<const double2*>(pm->u_prev), iu * 16u); }
+        mreg.nc = *at32(pm->hull_nc, iu * 4u);
         mreg.ha = make_double2(0.0, 0.0); mreg.hb = 0.0;
-        if (j < WCQP_HULL_ROWS) { mreg.ha = reinterpret_cast<const double2*>(pm->hull_A)[inst * WCQP_HULL_ROWS + j]; mreg.hb = pm->hull_b[inst * WCQP_HULL_ROWS + j]; }
+        if (j < WCQP_HULL_ROWS) {
+            mreg.ha = *at32(reinterpret_cast<const double2*>(pm->hull_A), (iu * WCQP_HULL_ROWS + (unsigned)j) * 16u);
+            mreg.hb = *at32(pm->hull_b, iu * (WCQP_HULL_ROWS * 8u) + j8);
+        }
         }
     }
     if constexpr (TICK) { if (do_mpc) wcqp_tick::tick_mpc_issue<KINF>(td, j, inst, tick_now + 1, mreg); else mreg.phase0 = td.phase0[inst]; }
@@ -228,33 +234,35 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     {
         // the state block first: vmcnt retires in order, and the rhs phase only needs the state, so the 36
         // Jacobian loads stay in flight underneath it
-        const double* sp = state + inst * kStateLen;
+        const unsigned so = iu * (unsigned)(kStateLen * 8);
+        const double* sp = at32(state, so + j8);                                         // entry m * 16 + j of the block: this lane's offset + an immediate
+        const double* sp5 = at32(state, so + 640u + (j < kStateLen - 80 ? j8 : 0u));     // entries 80 .. 86
         double sreg[6];
         if constexpr (!KINF) {
 #pragma unroll
-            for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
-            sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
+            for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16];
+            sreg[5] = sp5[0];
         }
         if constexpr (TICK) {
             // the tick kernel walks through the ticks: this lane's joint positions (and previous velocities) are carried from the
             // post step of one tick to the next in registers - what the post step stores is never re-read inside a launch
             q0 = carry[0]; q1 = carry[1];
         } else {
-            q0 = qpos[inst * kDof + j];
-            q1 = qpos[inst * kDof + (var1 ? col1 : 0)];
+            q0 = *at32(qpos, iu * (unsigned)(kDof * 8) + j8);
+            q1 = *at32(qpos, iu * (unsigned)(kDof * 8) + (var1 ? j8 + 128u : 0u));
         }
         auto load_measured_joints = [&]() {
-            if constexpr (EXT) { const double* qm = td.q_meas; qm0 = qm[inst * kDof + j]; qm1 = qm[inst * kDof + (var1 ? col1 : 0)]; }
+            if constexpr (EXT) { const double* qm = td.q_meas; qm0 = *at32(qm, iu * (unsigned)(kDof * 8) + j8); qm1 = *at32(qm, iu * (unsigned)(kDof * 8) + (var1 ? j8 + 128u : 0u)); }
         };
         if constexpr (TICK && !KINF) load_measured_joints();
         double g_com = 0.0, g_pstar = 0.0, g_vel = 0.0, g_twl = 0.0, g_twr = 0.0, g_ok = 1.0, g_sw = 0.0, g_h0 = 0.0;
         auto load_handoff = [&]() {
             // hand-off of MPC(t): desired CoM position / velocity (WalkingModule.cpp:686-695), the plant's CoM, did the MPC end usable
-            const double* hd = td.hand + ((size_t)(tick_now & 1) * td.batch + inst) * wcqp_tick::kHandLen;
-            const int ja = j & 1;
-            g_pstar = hd[ja]; g_vel = hd[2 + ja]; g_com = hd[4 + ja]; g_ok = hd[8];
-            g_sw = td.swing_twist[inst * 6 + (j < 6 ? j : 0)];
-            g_h0 = td.kin_mode ? td.com_h0[inst] : td.com_height;
+            const double* hb_ = at32(td.hand.get(), ((unsigned)(tick_now & 1) * (unsigned)td.batch + iu) * (unsigned)(wcqp_tick::kHandLen * 8));
+            const double* hd = at32(hb_, (unsigned)(j & 1) * 8u);
+            g_pstar = hd[0]; g_vel = hd[2]; g_com = hd[4]; g_ok = hb_[8];
+            g_sw = *at32(td.swing_twist.get(), iu * 48u + (j < 6 ? j8 : 0u));
+            g_h0 = td.kin_mode ? *at32(td.com_h0.get(), iu * 8u) : td.com_height;
         };
         if constexpr (TICK && !KINF) load_handoff();
         // the state / q loads above must ISSUE before the 36 column loads (vmcnt retires in order): hipcc otherwise sinks
@@ -284,7 +292,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 if (j < 8) { double* mh = S + K_MH + j * 3; mh[0] = mreg.ha.x; mh[1] = mreg.ha.y; mh[2] = mreg.hb; }
             }
             const int side = *gait >= td.step_ticks ? 1 : 0;          // (gait: this robot's cycle index (tick + phase0) % (2 step_ticks), carried from tick to tick) 0: left is the stance foot
-            if (j < 12) S[K_SD + j] = state[inst * kStateLen + 24 + side * 12 + j];                // desired pose of the anchor sole: p (3), R (9)
+            if (j < 12) S[K_SD + j] = *at32(state, iu * (unsigned)(kStateLen * 8) + (unsigned)(24 + side * 12) * 8u + j8);                // desired pose of the anchor sole: p (3), R (9)
             const int cs[2] = {j, var1 ? col1 : 0};
             double* TW = S + K_TW;
             int kup[2][3], ksub[2];                 // the joints' pointer-jumping links and subtree ends: from the model table in LDS
@@ -504,8 +512,8 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             __builtin_amdgcn_sched_barrier(0);
             // the pose block, the per-lane constants and the hand-off record: on their way under the MPC arithmetic below
 #pragma unroll
-            for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16 + j];
-            sreg[5] = sp[80 + (j < kStateLen - 80 ? j : 0)];
+            for (int m = 0; m < 5; ++m) sreg[m] = sp[m * 16];
+            sreg[5] = sp5[0];
             WCQP_STAMP(12);
             load_lane_constants();
             load_handoff();
@@ -550,18 +558,20 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         } else {
         const int fc0 = 6 + j;
         const int fc1 = var1 ? 22 + j : (base1 ? j - 8 : 0);
-        const double* jl = JL + inst * (6 * kNV);
-        const double* jr = JR + inst * (6 * kNV);
-        const double* jc = JC + inst * (3 * kNV);
-        const double* jn = JN + inst * (3 * kNV);
+        // per array two lane offsets (this lane's two columns of the instance's block), the rows behind them as immediates
+        const unsigned o6 = iu * (unsigned)(6 * kNV * 8), o3 = iu * (unsigned)(3 * kNV * 8), c0b = (unsigned)fc0 * 8u, c1b = (unsigned)fc1 * 8u;
+        const double* jl0 = at32(JL, o6 + c0b), *jl1 = at32(JL, o6 + c1b);
+        const double* jr0 = at32(JR, o6 + c0b), *jr1 = at32(JR, o6 + c1b);
+        const double* jc0 = at32(JC, o3 + c0b), *jc1 = at32(JC, o3 + c1b);
+        const double* jn0 = at32(JN, o3 + c0b), *jn1 = at32(JN, o3 + c1b);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) { a0[r] = jl[r * kNV + fc0]; a1[r] = jl[r * kNV + fc1]; }
+        for (int r = 0; r < 6; ++r) { a0[r] = jl0[r * kNV]; a1[r] = jl1[r * kNV]; }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) { a0[6 + r] = jr[r * kNV + fc0]; a1[6 + r] = jr[r * kNV + fc1]; }
+        for (int r = 0; r < 6; ++r) { a0[6 + r] = jr0[r * kNV]; a1[6 + r] = jr1[r * kNV]; }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { a0[12 + r] = jc[r * kNV + fc0]; a1[12 + r] = jc[r * kNV + fc1]; }
+        for (int r = 0; r < 3; ++r) { a0[12 + r] = jc0[r * kNV]; a1[12 + r] = jc1[r * kNV]; }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { a0[15 + r] = jn[r * kNV + fc0]; a1[15 + r] = jn[r * kNV + fc1]; }
+        for (int r = 0; r < 3; ++r) { a0[15 + r] = jn0[r * kNV]; a1[15 + r] = jn1[r * kNV]; }
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PAIR) {
@@ -579,10 +589,10 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             if (j == 0) wcqp_mpc::mpc_row_add_state(pm->c, p_xs, p_up, ux, uy);
             wcqp_mpc::mpc_row_finish(pm->c, j, ux, uy, mreg.nc, mreg.ha.x, mreg.ha.y, mreg.hb, reinterpret_cast<double (*)[4]>(S + OFF_COL), u0x, u0y, mst_, mact, margin);
             if (j == 0 && live) {
-                reinterpret_cast<double2*>(pm->u0)[inst] = make_double2(u0x, u0y);
-                pm->status[inst] = mst_;
-                if (pm->active) pm->active[inst] = mact;
-                if (pm->margin) pm->margin[inst] = margin;
+                *at32(reinterpret_cast<double2*>(pm->u0), iu * 16u) = make_double2(u0x, u0y);
+                *at32(pm->status, iu * 4u) = mst_;
+                if (pm->active) *at32(pm->active, iu * 4u) = mact;
+                if (pm->margin) *at32(pm->margin, iu * 8u) = margin;
             }
         }
         if constexpr (TICK) {
@@ -1450,15 +1460,16 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         dq0 = 0.0; dq1 = 0.0;
     }
     if (live) {
-        dq_out[inst * kDof + j] = dq0;
-        if (var1) dq_out[inst * kDof + col1] = dq1;
+        double* dqo = at32(dq_out, iu * (unsigned)(kDof * 8) + j8);
+        dqo[0] = dq0;
+        if (var1) dqo[16] = dq1;
         if (j == 0) {
             const unsigned up = (unsigned)((bu0 >> (16 * grp)) & 0xffffull) | ((unsigned)((bu1 >> (16 * grp)) & 0x7full) << 16);
             const unsigned dn = (unsigned)((bl0 >> (16 * grp)) & 0xffffull) | ((unsigned)((bl1 >> (16 * grp)) & 0x7full) << 16);
-            status_out[inst] = st_code;
-            if (aup_out) aup_out[inst] = use ? up : 0u;
-            if (alo_out) alo_out[inst] = use ? dn : 0u;
-            if (iters_out) iters_out[inst] = it;
+            *at32(status_out, iu * 4u) = st_code;
+            if (aup_out) *at32(aup_out, iu * 4u) = use ? up : 0u;
+            if (alo_out) *at32(alo_out, iu * 4u) = use ? dn : 0u;
+            if (iters_out) *at32(iters_out, iu * 4u) = it;
         }
     }
 #ifdef WCQP_IK_STAMPS
@@ -1474,12 +1485,13 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const double v0 = (ik_ok && !stopped) ? dq0 : 0.0, v1 = (ik_ok && !stopped) ? dq1 : 0.0;
             carry[0] += 0.5 * td.dT * (v0 + carry[2]); carry[2] = v0;
             const size_t g0 = (size_t)i_ * kDof + j;
-            td.q_des[g0] = carry[0]; td.dq_prev[g0] = v0;
+            double* qd = at32(td.q_des.get(), iu * (unsigned)(kDof * 8) + j8), *dp = at32(td.dq_prev.get(), iu * (unsigned)(kDof * 8) + j8);
+            qd[0] = carry[0]; dp[0] = v0;
             if (tick_now < td.log_ticks) td.dq_log[(size_t)tick_now * td.batch * kDof + g0] = v0;
             if (var1) {
                 carry[1] += 0.5 * td.dT * (v1 + carry[3]); carry[3] = v1;
                 const size_t g1 = (size_t)i_ * kDof + col1;
-                td.q_des[g1] = carry[1]; td.dq_prev[g1] = v1;
+                qd[16] = carry[1]; dp[16] = v1;
                 if (tick_now < td.log_ticks) td.dq_log[(size_t)tick_now * td.batch * kDof + g1] = v1;
             }
             if (j == 0 && (!ik_ok || stopped)) td.ik_fail[i_] += 1;       // tick_post_instance without the contact pair: the MPC part derives its own

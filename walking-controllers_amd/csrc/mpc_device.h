@@ -52,7 +52,8 @@ __device__ __forceinline__ int row_move(int v) { return __builtin_amdgcn_update_
 struct MpcLoads {
     double2 r[4], g0[4], g1[4];
 };
-__device__ __forceinline__ void mpc_window_loads(const MpcDeviceConsts& c, int t, const double2* __restrict__ rp, int ref_len, MpcLoads& L)
+// (ref: the batch's reference array, w0: element index of the first stage of this instance's window - 32-bit addressing, wcqp::at32)
+__device__ __forceinline__ void mpc_window_loads(const MpcDeviceConsts& c, int t, const double2* __restrict__ ref, unsigned w0, int ref_len, MpcLoads& L)
 {
     const double2* gp = reinterpret_cast<const double2*>(c.Gr.get());
 #pragma unroll
@@ -60,8 +61,9 @@ __device__ __forceinline__ void mpc_window_loads(const MpcDeviceConsts& c, int t
         const int i = t + k * kLanesPerInstance;
         const int ic = i <= c.N ? i : c.N;                // clamped: stays in bounds, weight zeroed in mpc_row_partial
         const int ir = ic < ref_len ? ic : ref_len - 1;   // MPCSolver.cpp:200-214 (constant tail)
-        L.r[k] = rp[ir];
-        L.g0[k] = gp[2 * ic]; L.g1[k] = gp[2 * ic + 1];
+        L.r[k] = *wcqp::at32(ref, (w0 + (unsigned)ir) * 16u);
+        const double2* g = wcqp::at32(gp, (unsigned)ic * 32u);
+        L.g0[k] = g[0]; L.g1[k] = g[1];
     }
 }
 // this lane's partial sum of u0_unc from the loaded window (partial, extra passes, then mpc_row_add_state on lane 0: the
@@ -77,14 +79,14 @@ __device__ __forceinline__ void mpc_row_partial(const MpcDeviceConsts& c, int t,
 }
 // the same with the gain blocks read from a copy of Gr in LDS at the time of use instead of being held in registers from
 // the time of the loads (the tick kernel with fused kinematics: 32 VGPRs less across its kinematics phase); bit-identical
-__device__ __forceinline__ void mpc_window_loads_ref_only(const MpcDeviceConsts& c, int t, const double2* __restrict__ rp, int ref_len, MpcLoads& L)
+__device__ __forceinline__ void mpc_window_loads_ref_only(const MpcDeviceConsts& c, int t, const double2* __restrict__ ref, unsigned w0, int ref_len, MpcLoads& L)
 {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = t + k * kLanesPerInstance;
         const int ic = i <= c.N ? i : c.N;
         const int ir = ic < ref_len ? ic : ref_len - 1;
-        L.r[k] = rp[ir];
+        L.r[k] = *wcqp::at32(ref, (w0 + (unsigned)ir) * 16u);
     }
 }
 __device__ __forceinline__ void mpc_row_partial_lds(const MpcDeviceConsts& c, int t, const MpcLoads& L, const double* gr_lds, double& ux, double& uy) {

@@ -95,6 +95,7 @@ struct wcqp_tick_s {
     hipEvent_t splice_done = nullptr; bool splice_pending = false;
     bool external = false, feedback_set = false;     // wcqp_tick_params.plant = EXTERNAL: one tick per run call, each behind a set_feedback
     double* q_meas = nullptr;
+    double* fb_stage = nullptr;   // wcqp_tick_set_feedback_host: [B][2 + 2 + 2 + dof]
 };
 
 namespace {
@@ -225,7 +226,7 @@ int wcqp_tick_create(const wcqp_tick_params* params, wcqp_tick_t* out) {
     const bool compact = masks_ok && !fusedk && params->kin_handoff != WCQP_KIN_HANDOFF_DENSE;
     // external feedback: the default (base-eliminated) kernel with constant Jacobians or fused kinematics, without logger rows
     if (h->external && (!d.skew || params->logger_ticks > 0 || (h->kin && !fusedk))) { wcqp_tick_destroy(h); return WCQP_E_UNSUPPORTED; }
-    if (h->external) { A_(h->q_meas, B * kDof); d.q_meas = h->q_meas; }
+    if (h->external) { A_(h->q_meas, B * kDof); d.q_meas = h->q_meas; A_(h->fb_stage, B * (6 + kDof)); }
     if (d.skew) {
         A_(d.mst, B * 16); A_(d.hand, 2 * B * kHandLen); A_(d.live_A, B * 16); A_(d.live_b, B * 8); A_(d.live_nc, B); A_(d.sel_built, B);
         if (compact) A_(jcomp, B * (size_t)cstride);
@@ -354,6 +355,20 @@ int wcqp_tick_set_feedback_device(wcqp_tick_t h, const double* dcm_meas, const d
     WCQP_HIP_TRY(hipGetLastError());
     h->feedback_set = true;
     return WCQP_OK;
+}
+
+int wcqp_tick_set_feedback_host(wcqp_tick_t h, const double* dcm_meas, const double* com_meas, const double* zmp_meas, const double* q_meas) {
+    if (!h || !dcm_meas || !com_meas || !zmp_meas) return WCQP_E_INVALID;
+    if (!h->external) return WCQP_E_UNSUPPORTED;
+    const size_t B = (size_t)h->d.batch;
+    double* st = h->fb_stage;
+    // (synchronous copies on the NULL stream: they wait for what the handle's last tick left running on a blocking stream, and the
+    // host arrays are consumed when they return)
+    WCQP_HIP_TRY(hipMemcpy(st, dcm_meas, B * 16, hipMemcpyHostToDevice));
+    WCQP_HIP_TRY(hipMemcpy(st + 2 * B, com_meas, B * 16, hipMemcpyHostToDevice));
+    WCQP_HIP_TRY(hipMemcpy(st + 4 * B, zmp_meas, B * 16, hipMemcpyHostToDevice));
+    if (q_meas) WCQP_HIP_TRY(hipMemcpy(st + 6 * B, q_meas, B * kDof * 8, hipMemcpyHostToDevice));
+    return wcqp_tick_set_feedback_device(h, st, st + 2 * B, st + 4 * B, q_meas ? st + 6 * B : nullptr, nullptr);
 }
 
 int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream) {

@@ -234,17 +234,20 @@ struct TickMpcRegs {
 // GAINS_LDS: the gain blocks Gr are read from a copy in LDS at the time of use (gr_lds), not loaded into registers here
 template <bool GAINS_LDS = false>
 __device__ __forceinline__ void tick_mpc_issue(const TickDev& d, int j, long inst, int t, TickMpcRegs& R) {
-    const double2* rp = reinterpret_cast<const double2*>(d.ref_traj.get()) + inst * d.traj_len + t;
-    R.phase0 = d.phase0[inst];
-    R.built = d.sel_built[inst];
-    const double2* sp = reinterpret_cast<const double2*>(d.mst.get() + (inst * 2 + (j & 1)) * 8);
+    // (32-bit addressing, wcqp::at32: wcqp_tick_create refuses batches whose trajectories do not fit 4 GB)
+    const unsigned iu = (unsigned)inst;
+    const double2* ref = reinterpret_cast<const double2*>(d.ref_traj.get());
+    const unsigned w0 = iu * (unsigned)d.traj_len + (unsigned)t;
+    R.phase0 = *wcqp::at32(d.phase0.get(), iu * 4u);
+    R.built = *wcqp::at32(d.sel_built.get(), iu * 4u);
+    const double2* sp = reinterpret_cast<const double2*>(wcqp::at32(d.mst.get(), (iu * 2u + (unsigned)(j & 1)) * 64u));
     R.s01 = sp[0]; R.s23 = sp[1]; R.s45 = sp[2]; R.s67 = sp[3];
-    if constexpr (GAINS_LDS) wcqp_mpc::mpc_window_loads_ref_only(d.mpc, j, rp, d.horizon + 1, R.L);
-    else wcqp_mpc::mpc_window_loads(d.mpc, j, rp, d.horizon + 1, R.L);
-    R.nc = d.live_nc[inst];
-    const int jr = j & 7;
-    R.ha = reinterpret_cast<const double2*>(d.live_A.get())[inst * WCQP_HULL_ROWS + jr];
-    R.hb = d.live_b[inst * WCQP_HULL_ROWS + jr];
+    if constexpr (GAINS_LDS) wcqp_mpc::mpc_window_loads_ref_only(d.mpc, j, ref, w0, d.horizon + 1, R.L);
+    else wcqp_mpc::mpc_window_loads(d.mpc, j, ref, w0, d.horizon + 1, R.L);
+    R.nc = *wcqp::at32(d.live_nc.get(), iu * 4u);
+    const unsigned jr = (unsigned)(j & 7);
+    R.ha = *wcqp::at32(reinterpret_cast<const double2*>(d.live_A.get()), (iu * WCQP_HULL_ROWS + jr) * 16u);
+    R.hb = *wcqp::at32(d.live_b.get(), (iu * WCQP_HULL_ROWS + jr) * 8u);
 }
 // tick_mpc_finish = tick_mpc_partial (this lane's share of u0_unc from the loaded window: the window registers die here) +
 // tick_mpc_finish_from (everything else, from the per-axis state records, the hull row and the partial sums)

@@ -76,6 +76,16 @@ __device__ __forceinline__ void pin_result(double& x) { __asm__ volatile("" : "+
 __device__ __forceinline__ void pin_value(int& x) { __asm__ volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin_value(unsigned& x) { __asm__ volatile("" : "+v"(x)); }
 
+// `base` + a 32-bit BYTE offset.  With a wave-uniform base (an SGPR pair: a kernel argument, or a pointer out of a record through
+// gptr.h) and a zero-extended 32-bit per-lane offset the access is `global_load ... v_off, s[base:base+1] offset:imm` - no 64-bit
+// VALU arithmetic at all, and constant element offsets behind it fold into the immediate.  Written as `ptr + long_index * stride`
+// the same address costs a 64-bit multiply-add and a 64-bit add per array (~8 VALU instructions each, ~150 per robot-tick record
+// in the solve kernels' load phase).  The caller guarantees that the offset fits 32 bits (the host entry points check batch x stride).
+template <class T>
+__device__ __forceinline__ const T* at32(const T* base, unsigned byte_off) { return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
+template <class T>
+__device__ __forceinline__ T* at32(T* base, unsigned byte_off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off); }
+
 // 1/x: v_rcp_f64 seed + two Newton steps (error <= ~1 ulp; the QPs need 1e-9, not
 // correctly-rounded division, and the IEEE division sequence is ~3x longer).
 __device__ __forceinline__ double fast_rcp(double x) {
