@@ -185,10 +185,11 @@ int wcqp_hull_from_feet_host(int32_t batch, const double* foot_rect,
 /* jacobian_structure: what the caller promises about the base blocks (columns 0..5) of the four Jacobians.
  * The reference always passes iDynTree free-floating Jacobians in MIXED representation
  * (WM/src/WalkingForwardKinematics.cpp:33, 436-454): J_left/J_right = [I B; 0 I | .], J_com = [I B | .],
- * J_neck (angular rows) = [0 I | .].  Algorithm 5 relies on that pattern and CHECKS it per instance: every identity / zero
- * entry within WCQP_IK_MIXED_TOL of 1.0 / 0.0 (a producer that forms the blocks through rotation products hands over
- * 0.9999999999999999; such an entry is then TREATED as exact, which moves the solution by at most
- * WCQP_IK_MIXED_TOL x |base velocity|).  Beyond the tolerance the instance does not have the pattern. */
+ * J_neck (angular rows) = [0 I | .].  Algorithm 5 relies on that pattern and CHECKS it per instance: for each of the six base
+ * columns the absolute deviations of its identity / zero entries from 1.0 / 0.0, summed over the four Jacobians, must not exceed
+ * WCQP_IK_MIXED_TOL (a producer that forms the blocks through rotation products hands over 0.9999999999999999; such entries are
+ * then TREATED as exact, which moves the solution by at most WCQP_IK_MIXED_TOL x |base velocity|).  Beyond the tolerance - or with
+ * a NaN in a base block - the instance does not have the pattern. */
 #define WCQP_IK_MIXED_TOL 1e-12
 #define WCQP_IK_JAC_AUTO    0    /* default: instances without the pattern are re-solved by the general kernel (one
                                     more, nearly empty, launch per call)                                          */

@@ -762,19 +762,22 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const int cb = j - 8;
             const bool lowc = cb < 3;
             const int cm = lowc ? cb : cb - 3;
+            // Within kMixedTol of the pattern counts as the pattern: a producer that forms the blocks through rotation products
+            // (R R' is I only to rounding) hands over 0.9999999999999999, and treating that entry as exactly 1 moves the
+            // solution by <= 1e-12 |v_base| - three orders inside the parity bar - instead of sending every instance to ik3.
+            // Measured as the sum of the absolute deviations of this base column's pattern entries (a NaN anywhere makes it NaN
+            // and the comparison false): linear columns [I; 0; I; 0; I; 0], angular columns [B; I; B; I; B; I] with B free.
+            const double mlo = lowc ? 1.0 : 0.0;
+            double dev = 0.0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                // Within kMixedTol of the pattern counts as the pattern: a producer that forms the blocks through rotation products
-                // (R R' is I only to rounding) hands over 0.9999999999999999, and treating that entry as exactly 1 moves the
-                // solution by <= 1e-12 |v_base| - three orders inside the parity bar - instead of sending every instance to ik3.
                 const double id = (r == cm) ? 1.0 : 0.0;
-                auto nr = [](double v, double w) { return fabs(v - w) <= kMixedTol; };        // (false for NaN)
-                const bool lo_ok = nr(a1[r], id) && nr(a1[3 + r], 0.0) && nr(a1[6 + r], id) && nr(a1[9 + r], 0.0) &&
-                                   nr(a1[12 + r], id) && nr(a1[15 + r], 0.0);
-                const bool hi_ok = nr(a1[3 + r], id) && nr(a1[9 + r], id) && nr(a1[15 + r], id);
-                pat = pat && (lowc ? lo_ok : hi_ok);
+                const double tang = lowc ? 0.0 : id;                        // what the three angular-row entries should be
+                dev += fabs(a1[3 + r] - tang) + fabs(a1[9 + r] - tang) + fabs(a1[15 + r] - tang);
+                dev = fma(mlo, fabs(a1[r] - id) + fabs(a1[6 + r] - id) + fabs(a1[12 + r] - id), dev);
                 if (!lowc) { db[r * 3 + cm] = a1[6 + r] - a1[r]; db[9 + r * 3 + cm] = a1[12 + r] - a1[r]; }
             }
+            pat = dev <= kMixedTol;
         }
     }
     const bool use = fast_ok != 0 && ((__ballot(!pat) >> (16 * grp)) & 0xffffull) == 0ull;
@@ -864,14 +867,20 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         const double* dv = S + OFF_DV;
         const bool rowok = j < NR, is12 = j == NR;
         const double dj = dv[j < NR ? j : 0];
+        // lane j < 12: row j of M (+ 1 on the first three diagonal entries); lane 12: -(C g~ + d); lanes 13..15: zeros - as ONE expression
+        // sgn (tile + m12 d) with per-lane constants sgn in {1, -1, 0}, m12 = [j == 12] (the tile's rows 13..15 are finite: zero rows of C^T)
+        const double sgn = rowok ? 1.0 : (is12 ? -1.0 : 0.0), m12 = is12 ? 1.0 : 0.0, mrow = rowok ? -1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < NR; k += 2) {
             const double2 d2 = ld2(dv + k);
             const double h0 = t[k & 3][k >> 2], h1 = t[(k + 1) & 3][(k + 1) >> 2];
-            Hr[k] = rowok ? h0 + ((k == j && k < 3) ? 1.0 : 0.0) : (is12 ? -(h0 + d2.x) : 0.0);
-            Hr[k + 1] = rowok ? h1 + ((k + 1 == j && k + 1 < 3) ? 1.0 : 0.0) : (is12 ? -(h1 + d2.y) : 0.0);
+            double v0 = fma(m12, d2.x, h0), v1 = fma(m12, d2.y, h1);
+            if (k < 3) v0 += (k == j) ? 1.0 : 0.0;
+            if (k + 1 < 3) v1 += (k + 1 == j) ? 1.0 : 0.0;
+            Hr[k] = sgn * v0;
+            Hr[k + 1] = sgn * v1;
         }
-        Hr[NR] = rowok ? -(t[NR & 3][NR >> 2] + dj) : 0.0;
+        Hr[NR] = mrow * (t[NR & 3][NR >> 2] + dj);
     }
 
     WCQP_STAMP(5);
@@ -908,10 +917,13 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const double idet = wcqp::fast_rcp(det);
             const double i11 = pd * idet, i12 = -pb * idet, i22 = pa * idet;
             const double m1 = Hr[k], m2 = Hr[k + 1];
-            const double g1 = fma(m1, i11, m2 * i12), g2 = fma(m1, i12, m2 * i22);     // rows other than k, k + 1
-            const bool isk = j == k, isk1 = j == k + 1;
-            const double f1 = isk ? 1.0 - i11 : (isk1 ? -i12 : g1);
-            const double f2 = isk ? -i12 : (isk1 ? 1.0 - i22 : g2);
+            const double g1 = fma(m1, i11, m2 * i12), g2 = fma(m1, i12, m2 * i22);     // rows k, k + 1 themselves: (1, 0), (0, 1) up to rounding
+            // The two pivot rows differ from the others by -(block inverse) in their update factors and by -1 on their own diagonal:
+            // written with the masks e_k = [j == k], e_k1 = [j == k + 1] (two FMAs each) instead of nested per-row selects (a select
+            // of a double is two v_cndmask: the sweep had 15 of them per block step, a quarter of its instructions)
+            const double ek = (j == k) ? 1.0 : 0.0, ek1 = (j == k + 1) ? 1.0 : 0.0;
+            const double f1 = fma(-ek1, i12, fma(-ek, i11, g1));
+            const double f2 = fma(-ek1, i22, fma(-ek, i12, g2));
             if (k + 2 < NR) {
                 Hr[k + 2] = fma(-f2, cb2[k + 2], fma(-f1, ca[k + 2], Hr[k + 2]));
                 Hr[k + 3] = fma(-f2, cb2[k + 3], fma(-f1, ca[k + 3], Hr[k + 3]));
@@ -925,8 +937,8 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 if (k + 2 < NR && (q == k + 2 || q == k + 3)) continue;
                 Hr[q] = fma(-f2, cb2[q], fma(-f1, ca[q], Hr[q]));
             }
-            Hr[k] = isk ? -i11 : (isk1 ? -i12 : g1);
-            Hr[k + 1] = isk ? -i12 : (isk1 ? -i22 : g2);
+            Hr[k] = f1 - ek;
+            Hr[k + 1] = f2 - ek1;
             // hipcc otherwise defers the updates of several steps (their factors stay alive: +100 VGPRs)
 #pragma unroll
             for (int q = 0; q <= NR; ++q) __asm__ volatile("" : "+v"(Hr[q]));

@@ -56,8 +56,8 @@ __device__ __forceinline__ double group_xor(double v) {
 // against ~70 cycles for a ds_swizzle pair.
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    const int lo = wcqp::dpp_dword<CTRL>(__double2loint(v));
+    const int hi = wcqp::dpp_dword<CTRL>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 // Row exchange inside a 32-lane group: v_permlane16_swap (new on gfx950) swaps the odd 16-lane rows
@@ -77,8 +77,8 @@ __device__ __forceinline__ void rows_pair(double v, double& d0, double& d1) {
 // one VALU move per dword, no LDS pipe.  SRC must be a compile-time constant.
 template <int SRC>
 __device__ __forceinline__ double row_bcast(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + (SRC & 15), 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + (SRC & 15), 0xf, 0xf, false);
+    const int lo = wcqp::dpp_dword<0x150 + (SRC & 15)>(__double2loint(v));
+    const int hi = wcqp::dpp_dword<0x150 + (SRC & 15)>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 // all-reduce over the 32 lanes of a group: four DPP steps inside each row of 16 (xor 1, xor 2 as

@@ -35,12 +35,12 @@ constexpr int kNumCand = 1 + 8 + 28;
 // One DPP move of both halves of a double inside a row of 16 lanes (= one instance here).
 template <int CTRL>
 __device__ __forceinline__ double row_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    const int lo = wcqp::dpp_dword<CTRL>(__double2loint(v));
+    const int hi = wcqp::dpp_dword<CTRL>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-__device__ __forceinline__ int row_move(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_move(int v) { return wcqp::dpp_dword<CTRL>(v); }
 // the four butterfly partners inside a row: xor 1, xor 2 (quad permutes), then half-mirror and
 // mirror, which pair quads / octets whose lanes already agree
 #define WCQP_ROW_STEPS(X) X(0xB1) X(0x4E) X(0x141) X(0x140)

@@ -76,6 +76,16 @@ __device__ __forceinline__ void pin_result(double& x) { __asm__ volatile("" : "+
 __device__ __forceinline__ void pin_value(int& x) { __asm__ volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin_value(unsigned& x) { __asm__ volatile("" : "+v"(x)); }
 
+// One dword through DPP.  For the controls whose every lane has a source inside its own row (quad_perm 0x00-0xff, row_mirror 0x140,
+// row_half_mirror 0x141, row_newbcast 0x150-0x15f) the "old" operand is never read: with update_dpp(0, ...) hipcc still materialises
+// that 0 in the destination in front of EVERY DPP move (two v_mov per double moved: a third of a butterfly step's instructions);
+// mov_dpp leaves it undefined.  Shifts (row_shl / row_shr: lanes without a source keep `old`) stay on update_dpp with old = 0.
+template <int CTRL>
+__device__ __forceinline__ int dpp_dword(int v) {
+    if constexpr (CTRL <= 0xFF || CTRL == 0x140 || CTRL == 0x141 || (CTRL >= 0x150 && CTRL <= 0x15F)) return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false);
+    else return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+
 // `base` + a 32-bit BYTE offset.  With a wave-uniform base (an SGPR pair: a kernel argument, or a pointer out of a record through
 // gptr.h) and a zero-extended 32-bit per-lane offset the access is `global_load ... v_off, s[base:base+1] offset:imm` - no 64-bit
 // VALU arithmetic at all, and constant element offsets behind it fold into the immediate.  Written as `ptr + long_index * stride`
