@@ -84,7 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--tick-cold-ik", action="store_true", help="tick workload: no IK hot start")
     ap.add_argument("--plan-ways", type=int, default=-1,
                     help="qp workload: W wavefronts share a robot group (way w takes steps w, w + W, ...; own outputs per way).  0 = one launch per step; "
-                         "-1 (default) = as many ways as put >= 20480 workgroups into the launch (10 x the card's resident wavefronts), at least 4, at most one per step")
+                         "-1 (default) = as many ways as put >= 16384 workgroups into the launch (8 x the card's resident wavefronts), at least 4, at most one per step")
     ap.add_argument("--plan-queue", type=int, choices=[0, 1], default=0, help="plan mode: 1 = (step, robot group) units from a device-side work queue instead of fixed ways")
     ap.add_argument("--resident-pass", action="store_true", help="plan mode: also time the dominant kernel re-reading ONE input set (frac_resident_inputs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -251,9 +251,10 @@ def bench_qp(c):
     exch_value = bool(args.exchange)                          # --exchange: the timed steps themselves carry the exchange
     use_plan = args.plan_ways != 0 and args.ik_jac == "mixed" and not exch_value
     if args.plan_ways < 0:
-        # enough workgroups for the hardware's dispatcher to even out the launch's ends (10 x the 2048 resident wavefronts), at
-        # least 4, at most one per step: 20 at 4096 robots, 5 at 16384, 4 from 20480 on (profiles/r03_plan_ways_20steps.txt)
-        args.plan_ways = int(max(1, min(S, max(4, -(-20480 // ((B + 3) // 4))))))
+        # enough workgroups for the hardware's dispatcher to even out the launch's ends (8 x the 2048 resident wavefronts), at
+        # least 4, at most one per step: 16 at 4096 robots, 4 from 16384 on (profiles/r03_plan_ways_20steps.txt; 20 ways at 4096
+        # robots were tried in round 4: 1.16e9 against 1.20e9 QP/s in the 20-step form)
+        args.plan_ways = int(max(1, min(S, max(4, -(-16384 // ((B + 3) // 4))))))
     # ---- input sets.  Every step of the run reads input arrays of its OWN (set k = the batch rotated by k B / K rows: same work,
     # other bytes at every address): a set that is read twice within ~256 MB of the card's reads comes out of the Infinity Cache
     # and the kernel then shows 0.62-0.66 of the roofline where it is 0.55.  R repeats x S steps + the warm-up

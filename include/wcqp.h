@@ -452,7 +452,7 @@ typedef struct wcqp_tick_params {
      *           its Jacobian columns (16 lanes per robot, two joints per lane) - one launch per tick, or many ticks per launch
      *           (ticks_per_launch).  Needs a tree whose joints each lie on the path of at most ONE of the three frames (left sole,
      *           right sole, neck: a humanoid whose legs and torso branch at the root link), depth-first joint numbering, depth
-     *           <= 8 and an MPC horizon <= 63; otherwise COMPACT is taken.
+     *           <= 8 and an MPC horizon <= 55; otherwise COMPACT is taken.
      * DENSE (1)   a kinematics launch per tick writes the four dense Jacobians (the layouts of wcqp_kin_jacobians_* /
      *           wcqp_ik_solve_*), 4.4 KB per robot of which ~70 % are structural zeros.
      * COMPACT (2) a kinematics launch per tick writes, per joint, its CoM column and its column of the ONE frame Jacobian

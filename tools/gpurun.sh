@@ -78,6 +78,74 @@ print("qp_plan_kernel per wave-record:", json.dumps(digest("plan_4096", "qp_plan
 print("ik4 fused tick per wave-tick:", json.dumps(digest("tickkin_8192", "ik4_tick_kernel", 224 * 2048)))
 PY
     ;;
+pipe)           # record-ahead Jacobian loads in the plan kernel: parity of the plan forms, then A/B against the same walk without them (WCQP_PLAN_NO_PIPE)
+    timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_bench_line.py -m gpu -q -x > $O/pytest.log 2>&1 || fail pytest $O/pytest.log
+    tail -1 $O/pytest.log
+    for rep in 1 2; do
+      for v in pipe nopipe; do
+        [ $v = nopipe ] && export WCQP_PLAN_NO_PIPE=1 || unset WCQP_PLAN_NO_PIPE
+        timeout -k 10 400 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-tick > $O/bench200_${v}_$rep.json 2> $O/bench200_${v}_$rep.err || fail "bench200 $v" $O/bench200_${v}_$rep.err
+        timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-tick > $O/bench20_${v}_$rep.json 2> $O/bench20_${v}_$rep.err || fail "bench20 $v" $O/bench20_${v}_$rep.err
+        timeout -k 10 400 python bench.py --steps 50 --warmup 10 --batch 65536 --no-cpu-baseline --no-tick > $O/bench65536_${v}_$rep.json 2> $O/bench65536_${v}_$rep.err || fail "bench65536 $v" $O/bench65536_${v}_$rep.err
+        last_json $O/bench200_${v}_$rep.json $O/bench20_${v}_$rep.json $O/bench65536_${v}_$rep.json
+      done
+    done
+    unset WCQP_PLAN_NO_PIPE
+    ;;
+twopass)        # single-batch latency form: one IK launch against a flagging pass + a compacted pass over the flagged robots (best case)
+    timeout -k 10 300 python tools/two_pass_timing.py > $O/two_pass.json 2> $O/two_pass.err || fail twopass $O/two_pass.err
+    cat $O/two_pass.json
+    ;;
+profiles)       # end-of-round evidence -> gpurun_out/r04/profiles/ (tools/r04_collect.py copies the summaries into profiles/r04_*)
+    R0=$PWD; cd /tmp && export TMPDIR=/tmp
+    prof() { # name, bench args...
+        n=$1; shift
+        timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R0/$O/prof_$n -- python3 $R0/bench.py --no-cpu-baseline "$@" > $R0/$O/prof_$n.log 2>&1 < /dev/null || fail "prof $n" $R0/$O/prof_$n.log
+        f=$(ls $R0/$O/prof_$n/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R0/$O/${n}_kernel_stats.csv
+        rm -rf $R0/$O/prof_$n
+        echo "profiled $n"
+    }
+    # (warm-up = steps: the warm-up steps are a plan launch of their own, and rocprofv3's average over the launches of the plan kernel is then over launches of ONE length)
+    prof bench_b4096_driver --steps 20 --warmup 20
+    prof bench_b4096 --steps 200 --warmup 200 --no-tick
+    prof bench_b65536 --steps 50 --warmup 50 --batch 65536 --no-tick
+    prof tick_kin_b8192 --workload tick --batch 8192 --steps 1000 --warmup 24
+    prof tick_tables_b8192 --workload tick --batch 8192 --steps 1000 --warmup 24 --tick-tables
+    # PMC: HBM traffic (FETCH_SIZE to be doubled on gfx950: MI355X_MICROARCH.md), one counter per pass; every plan-kernel launch of a run holds 88 / 24 records
+    for C in FETCH_SIZE WRITE_SIZE; do
+        timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R0/$O/pmc/bench_4096_$C -- python3 $R0/bench.py --steps 88 --warmup 88 --repeats 1 --batch 4096 --no-cpu-baseline --no-tick > $R0/$O/pmc_bench_4096_$C.log 2>&1 < /dev/null || fail "pmc $C 4096" $R0/$O/pmc_bench_4096_$C.log
+        timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R0/$O/pmc/bench_65536_$C -- python3 $R0/bench.py --steps 24 --warmup 24 --repeats 1 --batch 65536 --no-cpu-baseline --no-tick > $R0/$O/pmc_bench_65536_$C.log 2>&1 < /dev/null || fail "pmc $C 65536" $R0/$O/pmc_bench_65536_$C.log
+        timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R0/$O/pmc/tickkin_8192_$C -- python3 $R0/bench.py --workload tick --batch 8192 --steps 200 --warmup 24 --no-cpu-baseline > $R0/$O/pmc_tickkin_$C.log 2>&1 < /dev/null || fail "pmc $C tick" $R0/$O/pmc_tickkin_$C.log
+        timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R0/$O/pmc/ticktab_8192_$C -- python3 $R0/bench.py --workload tick --batch 8192 --steps 200 --warmup 24 --tick-tables --no-cpu-baseline > $R0/$O/pmc_ticktab_$C.log 2>&1 < /dev/null || fail "pmc $C ticktab" $R0/$O/pmc_ticktab_$C.log
+        echo "pmc $C"
+    done
+    P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU"
+    P2="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_MFMA"
+    n=1
+    for P in "$P1" "$P2"; do
+        timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R0/$O/pmc/plan_4096_p$n -- python3 $R0/bench.py --steps 88 --warmup 88 --repeats 1 --batch 4096 --no-cpu-baseline --no-tick > $R0/$O/pmc_plan_p$n.log 2>&1 < /dev/null || fail "pmc plan $n" $R0/$O/pmc_plan_p$n.log
+        timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R0/$O/pmc/tickkin_8192_p$n -- python3 $R0/bench.py --workload tick --batch 8192 --steps 200 --warmup 24 --no-cpu-baseline > $R0/$O/pmc_tickkin_p$n.log 2>&1 < /dev/null || fail "pmc tick $n" $R0/$O/pmc_tickkin_p$n.log
+        n=$((n+1))
+    done
+    cd $R0
+    python3 tools/pmc/summarize.py $O/pmc > $O/pmc_summary.json 2> $O/pmc_summary.err
+    python3 tools/pmc/make_traffic.py $O/pmc_summary.json > $O/traffic.json 2> $O/traffic.err
+    # the bench lines below quote roofline.traffic from profiles/traffic.json when its source hash is the current one: this run's own PMC passes
+    [ -s $O/traffic.json ] && cp $O/traffic.json profiles/traffic.json
+    rm -rf $O/pmc
+    # bench lines (no profiler attached)
+    timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > $O/bench_b4096_driver.json 2> $O/bench.err || fail "bench driver" $O/bench.err
+    timeout -k 10 600 python3 bench.py --steps 200 --warmup 20 --no-tick > $O/bench_b4096.json 2>> $O/bench.err || fail "bench 200" $O/bench.err
+    timeout -k 10 600 python3 bench.py --steps 100 --warmup 10 --batch 65536 --no-cpu-baseline --no-tick > $O/bench_b65536.json 2>> $O/bench.err || fail "bench 65536" $O/bench.err
+    timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-tick --plan-ways 0 > $O/bench_b4096_driver_launch_per_step.json 2>> $O/bench.err || fail "bench lps" $O/bench.err
+    timeout -k 10 600 python3 bench.py --steps 200 --warmup 20 --ik-form osqp --no-cpu-baseline --no-tick > $O/bench_b4096_osqp.json 2>> $O/bench.err || fail "bench osqp" $O/bench.err
+    timeout -k 10 600 python3 bench.py --steps 200 --warmup 20 --horizon 200 --no-cpu-baseline --no-tick > $O/bench_b4096_n200.json 2>> $O/bench.err || fail "bench n200" $O/bench.err
+    timeout -k 10 600 python3 bench.py --workload tick --batch 8192 --steps 1000 --warmup 24 --no-cpu-baseline > $O/bench_tick_kin_b8192.json 2>> $O/bench.err || fail "bench tick" $O/bench.err
+    timeout -k 10 600 python3 bench.py --workload tick --batch 8192 --steps 1000 --warmup 24 --no-cpu-baseline --tick-tables > $O/bench_tick_tables_b8192.json 2>> $O/bench.err || fail "bench ticktab" $O/bench.err
+    timeout -k 10 600 python3 bench.py --workload tick --batch 65536 --steps 200 --warmup 24 --no-cpu-baseline > $O/bench_tick_kin_b65536.json 2>> $O/bench.err || fail "bench tick 65536" $O/bench.err
+    WCQP_DIST_BACKEND=gloo timeout -k 10 600 python3 bench.py --gpus 2 --steps 20 --warmup 5 --tick-ticks 200 > $O/bench_gpus2_gloo_rehearsal.json 2>> $O/bench.err || fail "bench gpus 2" $O/bench.err
+    last_json $O/bench_*.json
+    ;;
 split)          # one combined plan against IK-only + MPC-only plans enqueued together, for the libraries given (product = "")
     for lib in "$@"; do
         tag=${lib:-product}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence: rocprofv3 kernel stats of the bench commands, PMC passes (separate runs, --kernel-trace only), bench lines.
 # Everything under gpurun_out/r03/; the summaries worth keeping are copied to profiles/r03_* by tools/r03_collect.py.
-#   gpurun --timeout 1100 -- 'bash tools/gpu_r03_profiles.sh'
+#   gpurun --timeout 1100 -- 'bash tools/history/r03_profiles.sh'
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 O=$R/gpurun_out/r03; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -6,7 +6,7 @@ def load(d):
     for f in glob.glob(os.path.join(root, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            short = ("qp_plan_kernel" if "qp_plan_kernel" in name else "tick_mpc_prime_kernel" if "tick_mpc_prime" in name else "ik4_tick_kernel" if "ik4_kernel<true" in name
+            short = ("qp_plan_kernel" if ("qp_plan_kernel" in name or "qp_plan_pipe_kernel" in name) else "tick_mpc_prime_kernel" if "tick_mpc_prime" in name else "ik4_tick_kernel" if "ik4_kernel<true" in name
                      else "qp_pair_kernel" if "qp_pair_kernel" in name else "ik4_kernel" if "ik4_kernel" in name else "kin_jacobians_kernel" if "kin_jacobians" in name else "ik3_kernel" if "ik3_kernel" in name else "ik2_kernel" if "ik2_kernel" in name else "ik_kernel" if "ik_kernel" in name
                      else "mpc_condensed_kernel" if "mpc_condensed" in name else name.split("(")[0][-30:])
             out[short][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -1,4 +1,4 @@
-"""Copies the round-3 evidence worth keeping from gpurun_out/r03/ (tools/gpu_r03_profiles.sh, tools/gpu_r03q.sh) into profiles/:
+"""Copies the round-3 evidence worth keeping from gpurun_out/r03/ (tools/history/r03_profiles.sh, tools/history/r03_tick_kernel_stats.sh) into profiles/:
 kernel stats CSVs, bench JSON lines, the PMC summary, traffic.json, and a per-wave digest of the detailed PMC passes."""
 import glob, json, os, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +37,7 @@ def digest(prefix, kern, units_per_launch, what, units_total=None):
             "raw_totals": c}
 
 
-out = {"note": "rocprofv3 --pmc passes of tools/gpu_r03_profiles.sh (one counter group per run, --kernel-trace only). per_wave_unit: counter totals over all "
+out = {"note": "rocprofv3 --pmc passes of tools/history/r03_profiles.sh (one counter group per run, --kernel-trace only). per_wave_unit: counter totals over all "
                "launches of the run / (workgroups x records or ticks they walked through); SQ_WAVE_CYCLES counts in units of 4 cycles.",
        # bench.py --steps 88: every qp_plan_kernel launch of the run (the timed one and the roofline pass's) walks through 88 records, 1024 robot groups
        "qp_plan_kernel_b4096": digest("plan_4096", "qp_plan_kernel", 88 * 1024, "one wave-record = the IK and the MPC of 4 robots of one step"),

@@ -31,7 +31,7 @@
 // C^T (k-major) stays in LDS from the Gram product to the end: the columns are re-read where they are needed (x~,
 // a bound's column tau_p) instead of occupying 48 VGPRs through the sweep, and the Gram tile reaches its row lanes
 // through v_permlane32_swap / v_permlane16_swap (a 4 x 4 block transpose across the wave's four DPP rows) instead of
-// an LDS tile.  LDS 408 doubles per instance (13 KB per block: 12 blocks per CU = 3 waves per SIMD).
+// an LDS tile.  LDS 440 doubles per instance (13.75 KB per block: 11 blocks per CU; two waves per SIMD need 8).
 // Template parameter TICK: the tick pipeline's glue / post steps fused in (tick_device.h).
 #include <cmath>
 #include <limits>
@@ -73,11 +73,20 @@ constexpr int OFF_CV = A_SIZE + 32;   // [16]
 constexpr int OFF_ROWB = A_SIZE + 48; // [16] row of the leaving slot
 //   variable of slot a (working sets of more than KS bounds): an int in entry 13 of row a of C^T (the zero row of the Gram
 //   tile, dead once the MFMAs have read it)
-constexpr int PER_INST = 408;         // = 24 mod 32: the four instances of a wave sit 16 banks apart; 13056 B per workgroup
+constexpr int PER_INST = 440;         // = 24 mod 32: the four instances of a wave sit 16 banks apart; 14080 B per workgroup (408 would do for the
+                                      // solve; the fused kinematics' joint frames want the rest: K_* below)
+// ---- fused kinematics (JSRC = 2): scratch of the kinematics phase, over the same region (everything of it is dead before the pose block
+// and C^T are written).  Joint frames [23][K_FS]: 12 doubles at a stride of 14 - the b128 accesses of 16 lanes then land on 8 distinct
+// groups of 4 banks (2 passes, the minimum for a b128) instead of 4 groups (4 passes) at a stride of 12: PMC showed 24 % of the tick
+// kernel's LDS-active cycles as bank conflicts.  The two spare doubles behind frames 16..21 hold the anchor pose (k_sd).
+constexpr int K_FS = 14, K_TW = 0, K_FRB = 322, K_FR = 358;          // joint frames, attached frames in base / world coordinates [3][12] each
+constexpr int K_MS = 394, K_MH = 410;                               // stashes: the MPC chain's per-axis records [2][8], its hull rows [8][3]
+__host__ __device__ constexpr int k_sd(int m) { return K_TW + (16 + (m >> 1)) * K_FS + 12 + (m & 1); }      // anchor pose [12] / CoM [3]
+static_assert(kDof * K_FS <= K_FRB && K_FR + 36 <= K_MS && K_MH + 24 <= PER_INST && k_sd(11) < kDof * K_FS && k_sd(0) >= 32 * 4, "kinematics scratch fits; the prefix sums [32][4] stay clear of the anchor pose");
 static_assert(OFF_CT + 24 * LDC + 2 <= A_SIZE && OFF_DB + 18 <= A_SIZE && OFF_PB + 12 * 18 <= A_SIZE, "LDS overlays");
 static_assert(OFF_ROWB + 16 <= PER_INST && OFF_DV + 16 <= PER_INST && (PER_INST % 32 == 24 || PER_INST % 32 == 8), "instances 16 banks apart");
 static_assert(KMAX <= 24, "one slot index per C^T row");
-static_assert(PER_INST * 8 * 4 * 12 <= 160 * 1024, "12 blocks per CU");
+static_assert(PER_INST * 8 * 4 * 11 <= 160 * 1024, "11 blocks per CU");
 
 #ifndef WCQP_IK4_WAVES
 #define WCQP_IK4_WAVES 2
@@ -275,10 +284,6 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             // the four MIXED Jacobians, straight into the registers the row operations read.  Same algebra as
             // kin_jacobians_kernel (kin.hip), laid out for the IK's 16 lanes per robot: lane j owns joints j and 16 + j.
             using namespace wcqp_kin;
-            constexpr int K_TW = 0, K_FRB = 276, K_FR = 312;     // joint frames [23][12], attached frames (base / world) [3][12] each
-            static_assert(K_FR + 36 <= PER_INST && kDof * 12 <= K_FRB, "kinematics scratch fits the instance's LDS");
-            constexpr int K_MS = 348, K_MH = 364, K_SD = 388;      // stashes (the sweep's region B is idle): MPC per-axis records [2][8], MPC hull rows [8][3], anchor pose [12]
-            static_assert(K_SD + 12 <= PER_INST, "stashes fit");
             // every register counts across this phase: what the MPC chain of tick t + 1 has loaded is reduced to this lane's share
             // of u0_unc now (its loads were issued first: they have landed when the pose block below has) and its per-axis records
             // and hull row wait in LDS; the pose block is re-read behind the kinematics (L2) instead of being held
@@ -292,7 +297,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 if (j < 8) { double* mh = S + K_MH + j * 3; mh[0] = mreg.ha.x; mh[1] = mreg.ha.y; mh[2] = mreg.hb; }
             }
             const int side = *gait >= td.step_ticks ? 1 : 0;          // (gait: this robot's cycle index (tick + phase0) % (2 step_ticks), carried from tick to tick) 0: left is the stance foot
-            if (j < 12) S[K_SD + j] = *at32(state, iu * (unsigned)(kStateLen * 8) + (unsigned)(24 + side * 12) * 8u + j8);                // desired pose of the anchor sole: p (3), R (9)
+            if (j < 12) S[k_sd(j)] = *at32(state, iu * (unsigned)(kStateLen * 8) + (unsigned)(24 + side * 12) * 8u + j8);                // desired pose of the anchor sole: p (3), R (9)
             const int cs[2] = {j, var1 ? col1 : 0};
             double* TW = S + K_TW;
             int kup[2][3], ksub[2];                 // the joints' pointer-jumping links and subtree ends: from the model table in LDS
@@ -322,7 +327,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
                     if (s_ == 0 || var1) {
-                        double* Tm = TW + cs[s_] * 12;
+                        double* Tm = TW + cs[s_] * K_FS;
 #pragma unroll
                         for (int k = 0; k < 8; k += 2) st2(Tm + k, Ra[s_][k], Ra[s_][k + 1]);
                         st2(Tm + 8, Ra[s_][8], pa[s_][0]); st2(Tm + 10, pa[s_][1], pa[s_][2]);
@@ -333,7 +338,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 for (int s_ = 0; s_ < 2; ++s_) {
                     const int u = kup[s_][r];
                     if (u >= 0 && (s_ == 0 || var1)) {
-                        const double* T = TW + u * 12;
+                        const double* T = TW + u * K_FS;
                         double Rp[9], pp[3], Rn[9], pn[3];
 #pragma unroll
                         for (int k = 0; k < 9; ++k) Rp[k] = T[k];
@@ -351,7 +356,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) {
                 if (s_ == 0 || var1) {
-                    double* Tm = TW + cs[s_] * 12;
+                    double* Tm = TW + cs[s_] * K_FS;
 #pragma unroll
                     for (int k = 0; k < 8; k += 2) st2(Tm + k, Ra[s_][k], Ra[s_][k + 1]);
                     st2(Tm + 8, Ra[s_][8], pa[s_][0]); st2(Tm + 10, pa[s_][1], pa[s_][2]);
@@ -363,7 +368,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             const int fi = j < 3 ? j : 0;
             double Rf[9], pf[3];
             {
-                const double* T = TW + kfj * 12;
+                const double* T = TW + kfj * K_FS;
                 const double* ft = kmodel + wcqp_tick::kKinTabFrames + fi * 12;
                 double Rj[9], pj[3], fR[9], fp[3];
 #pragma unroll
@@ -386,9 +391,9 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* Fs = S + K_FRB + side * 12;
                 double Rs[9], ps[3], d3[3], sdp[3], sdR[9];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) sdp[k] = S[K_SD + k];
+                for (int k = 0; k < 3; ++k) sdp[k] = S[k_sd(k)];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) sdR[k] = S[K_SD + 3 + k];
+                for (int k = 0; k < 9; ++k) sdR[k] = S[k_sd(3 + k)];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) Rs[k] = Fs[k];
 #pragma unroll
@@ -418,7 +423,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 const double* mt = kmodel + cs[s_] * wcqp_tick::kKinTabJoint;
                 double Rw[9], cl[3], Rl[9], pl[3];
                 {   // the joint's frame in base coordinates, back from LDS (not held in registers across the frames / base pose above)
-                    const double* Tm = TW + cs[s_] * 12;
+                    const double* Tm = TW + cs[s_] * K_FS;
 #pragma unroll
                     for (int k = 0; k < 9; ++k) Rl[k] = Tm[k];
 #pragma unroll
@@ -507,7 +512,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             // (the attached frames in world coordinates stay in LDS - they are the ACTUAL poses the pose block gets below - and the
             // CoM joins them in the anchor pose's stash, which is dead)
             wcqp::wave_lds_fence();
-            if (j < 3) S[K_SD + j] = ctot[j];
+            if (j < 3) S[k_sd(j)] = ctot[j];
             // (pinned: hipcc otherwise hoists these loads - 44 registers of results - to the top of the kinematics phase)
             __builtin_amdgcn_sched_barrier(0);
             // the pose block, the per-lane constants and the hand-off record: on their way under the MPC arithmetic below
@@ -601,7 +606,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 // (hull rows in the MPC stash's place, just read back: the attached frames at 312..347 are still needed)
                 const int cyc1 = *gait + 1 == 2 * td.step_ticks ? 0 : *gait + 1;
                 const int code1 = wcqp_tick::contact_code_cyc(cyc1, td.step_ticks, td.ds_ticks);
-                if constexpr (KINF) wcqp_tick::tick_mpc_finish_from(td, j, inst, live, tick_now + 1, mreg, m_r0, m_ux, m_uy, reinterpret_cast<double (*)[4]>(S + 348), code1, noise_base);
+                if constexpr (KINF) wcqp_tick::tick_mpc_finish_from(td, j, inst, live, tick_now + 1, mreg, m_r0, m_ux, m_uy, reinterpret_cast<double (*)[4]>(S + K_MS), code1, noise_base);
                 else wcqp_tick::tick_mpc_finish(td, j, inst, live, tick_now + 1, mreg, reinterpret_cast<double (*)[4]>(S + OFF_COL), nullptr, code1, noise_base);
             }
             if (j < 6) {
@@ -625,14 +630,13 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
         if constexpr (KINF) {
             // the ACTUAL poses the kinematics phase produced (WalkingModule.cpp:396-410) over the pose block's
             wcqp::wave_lds_fence();
-            constexpr int K_FR = 312, K_SD = 388;
             if (j < 12) {
                 const double* FL = S + K_FR, *FRt = S + K_FR + 12;
                 st[j] = j < 3 ? FL[9 + j] : FL[j - 3];
                 st[12 + j] = j < 3 ? FRt[9 + j] : FRt[j - 3];
             }
             if (j < 9) st[48 + j] = S[K_FR + 24 + j];
-            if (j < 3) st[66 + j] = S[K_SD + j];
+            if (j < 3) st[66 + j] = S[k_sd(j)];
         }
         if constexpr (TICK) {
             wcqp::wave_lds_fence();

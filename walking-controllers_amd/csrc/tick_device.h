@@ -85,7 +85,7 @@ struct TickDev {
 constexpr int kHandLen = 14;
 constexpr int kLoggerCols = 53;
 constexpr int kKinTabJoint = 22, kKinTabInts = 19, kKinTabFrames = kKinTabJoint * kDof, kKinTabRoot = kKinTabFrames + 36, kKinTabSize = kKinTabRoot + 6;
-constexpr int kGainsLdsStages = 64;        // fused kinematics: the MPC's gain blocks Gr ((N + 1) x 2 x 2, N <= 63) sit in LDS beside the model
+constexpr int kGainsLdsStages = 56;        // fused kinematics: the MPC's gain blocks Gr ((N + 1) x 2 x 2, N <= 55) sit in LDS beside the model (56: what 8 workgroups per CU leave)
 
 // offset (doubles) of joint c's record inside a robot's compact Jacobian block, and the frame the joint belongs to
 // (0 none, 1 left sole, 2 right sole, 3 neck): records are 4 (CoM column only), 6 (+ neck angular) or 10 (+ a foot's 6) long
