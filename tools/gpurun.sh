@@ -133,6 +133,9 @@ profiles)       # end-of-round evidence -> gpurun_out/r04/profiles/ (tools/r04_c
     # the bench lines below quote roofline.traffic from profiles/traffic.json when its source hash is the current one: this run's own PMC passes
     [ -s $O/traffic.json ] && cp $O/traffic.json profiles/traffic.json
     rm -rf $O/pmc
+    ;;
+benchlines)     # the round's bench lines, no profiler attached (after `profiles`, with its traffic.json copied into profiles/ by tools/r04_collect.py)
+    O=gpurun_out/$R/profiles; mkdir -p $O
     # bench lines (no profiler attached)
     timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > $O/bench_b4096_driver.json 2> $O/bench.err || fail "bench driver" $O/bench.err
     timeout -k 10 600 python3 bench.py --steps 200 --warmup 20 --no-tick > $O/bench_b4096.json 2>> $O/bench.err || fail "bench 200" $O/bench.err

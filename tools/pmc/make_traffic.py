@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import walking_controllers_amd as wca
 d = json.load(open(sys.argv[1]))
 IK, MPC = 5240, 1056
-out = {"note": "HBM-side bytes from rocprofv3 PMC (separate passes: tools/history/r03_profiles.sh, summary in profiles/r03_pmc_summary.json). "
+out = {"note": "HBM-side bytes from rocprofv3 PMC (separate passes: tools/gpurun.sh profiles, summary in profiles/r04_pmc_summary.json). "
                "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed bytes; calibrated in "
                "round 1 on tools/pmc/pmc_calib.hip: 512 MiB streamed with 8 B/lane and 16 B/lane reads report x0.5000, 29-wide rows x0.517, writes exact). "
                "qp_plan_kernel: per STEP (every launch of the PMC runs holds `records_per_launch` records); tick kernels: per TICK (all launches / all ticks).",

@@ -19,6 +19,8 @@ for f in glob.glob(os.path.join(O, "bench_*.json")):
         open(os.path.join(P, "r04_" + os.path.basename(f)), "w").write(ln + "\n")
 if os.path.exists(os.path.join(O, "pmc_summary.json")):
     shutil.copy(os.path.join(O, "pmc_summary.json"), os.path.join(P, "r04_pmc_summary.json"))
+    if os.path.exists(os.path.join(O, "traffic.json")) and os.path.getsize(os.path.join(O, "traffic.json")) > 0:
+        shutil.copy(os.path.join(O, "traffic.json"), os.path.join(P, "traffic.json"))
     d = json.load(open(os.path.join(O, "pmc_summary.json")))
 
     def digest(prefix, kern, units, what):
