@@ -78,7 +78,9 @@ print("qp_plan_kernel per wave-record:", json.dumps(digest("plan_4096", "qp_plan
 print("ik4 fused tick per wave-tick:", json.dumps(digest("tickkin_8192", "ik4_tick_kernel", 224 * 2048)))
 PY
     ;;
-pipe)           # record-ahead Jacobian loads in the plan kernel: parity of the plan forms, then A/B against the same walk without them (WCQP_PLAN_NO_PIPE)
+pipe)           # record-ahead Jacobian loads in the plan kernel, A/B against the same walk without them (WCQP_PLAN_NO_PIPE). NEEDS profiles/r04_record_ahead.patch
+                # applied to csrc/ik4.hip (git apply) and a rebuild: the experiment was negative and the code is not in the tree (profiles/r04_record_ahead_ab.txt)
+    grep -q WCQP_PLAN_NO_PIPE walking-controllers_amd/csrc/*.hip || { echo 'pipe: apply profiles/r04_record_ahead.patch and rebuild first'; exit 1; }
     timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_bench_line.py -m gpu -q -x > $O/pytest.log 2>&1 || fail pytest $O/pytest.log
     tail -1 $O/pytest.log
     for rep in 1 2; do
