@@ -229,3 +229,44 @@ def test_same_algorithm_cpu_legs_match_the_goldens(qs, wca, golden_dir):
         assert np.abs(dq[ok] - g["dq"][ok]).max() <= 1e-10
         cc = (g["mu_min_active"] > 1e-7) & (g["slack_min_inactive"] > 1e-7) & ok
         assert np.array_equal(lo[cc], g["active_lower"][cc]) and np.array_equal(up[cc], g["active_upper"][cc])
+
+
+# ---- the solver restatements against the third-party libraries' PUBLISHED example problems --------
+# The reference holds no fixture, and the libraries its two QPs are handed to (OSQP through osqp-eigen:
+# WM/src/MPCSolver.cpp:68-80, WM/src/WalkingQPInverseKinematics_osqp.cpp:27-40; qpOASES: WM/src/WalkingQPInverseKinematics_qpOASES.cpp:
+# 303-335) are not vendored.  What those libraries publish with a stated answer are their own first examples; the oracle's solvers
+# (the exact active-set walk with its KKT certificate, the C restatement of the OSQP iteration) must reproduce them.  This pins the
+# SOLVERS the goldens come from to an answer that is not this repository's own; it says nothing about the reference's assembly.
+def test_solvers_on_the_osqp_documentation_demo(qs):
+    """OSQP's setup-and-solve demo (the problem every language binding's README solves):
+        min 1/2 x'[[4,1],[1,2]]x + [1,1]'x   s.t.  1 <= x1 + x2 <= 1,  0 <= x1 <= 0.7,  0 <= x2 <= 0.7
+    published optimum x = (0.3, 0.7), objective 1.88."""
+    from oracle import c_oracle as co
+    P = np.array([[4.0, 1.0], [1.0, 2.0]]); q = np.array([1.0, 1.0])
+    A = np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]]); l = np.array([1.0, 0.0, 0.0]); u = np.array([1.0, 0.7, 0.7])
+    x, it, rc = co.osqp_dense(P, q, A, l, u)                                  # library defaults: eps 1e-3 on the RESIDUALS, 25 iterations
+    assert rc == 0 and np.abs(x - [0.3, 0.7]).max() < 3e-3 and abs(0.5 * x @ P @ x + q @ x - 1.88) < 1e-3
+    x, it, rc = co.osqp_dense(P, q, A, l, u, eps_abs=1e-10, eps_rel=1e-10, max_iter=20000)
+    assert rc == 0 and np.abs(x - [0.3, 0.7]).max() < 1e-8
+    assert abs(0.5 * x @ P @ x + q @ x - 1.88) < 1e-8
+    Ain = np.vstack([A[1:], -A[1:]]); bin_ = np.concatenate([u[1:], -l[1:]])
+    xe, lam, mu, act = qs.qp_exact(P, q, A[:1], l[:1], Ain, bin_)
+    assert np.abs(xe - [0.3, 0.7]).max() < 1e-13 and act == [1]               # x2 at its upper bound
+
+
+def test_solvers_on_the_qpoases_manual_example(qs):
+    """qpOASES' example1 (examples/example1.cpp, the manual's first QP):
+        H = diag(1, 0.5), g = (1.5, 1), 0.5 <= x1 <= 5, -2 <= x2 <= 2, -1 <= x1 + x2 <= 2
+    published: x = (0.5, -1.5), objective -6.25e-02; and its hot-started second QP g = (1, 1.5), 0 <= x1 <= 5, -1 <= x2 <= 2,
+    -2 <= x1 + x2 <= 1: x = (0, -1), objective -1.25."""
+    from oracle import c_oracle as co
+    H = np.diag([1.0, 0.5]); A = np.array([[1.0, 1.0]])
+    I2 = np.eye(2)
+    for g, lb, ub, lbA, ubA, xs, obj in ((np.array([1.5, 1.0]), [0.5, -2.0], [5.0, 2.0], -1.0, 2.0, [0.5, -1.5], -6.25e-2),
+                                         (np.array([1.0, 1.5]), [0.0, -1.0], [5.0, 2.0], -2.0, 1.0, [0.0, -1.0], -1.25)):
+        Ain = np.vstack([I2, -I2, A, -A]); bin_ = np.array([ub[0], ub[1], -lb[0], -lb[1], ubA, -lbA])
+        x, lam, mu, act = qs.qp_exact(H, g, np.zeros((0, 2)), np.zeros(0), Ain, bin_)
+        assert np.abs(x - xs).max() < 1e-13 and abs(0.5 * x @ H @ x + g @ x - obj) < 1e-13
+        xo, it, rc = co.osqp_dense(H, g, np.vstack([I2, A]), np.array([lb[0], lb[1], lbA]), np.array([ub[0], ub[1], ubA]),
+                                   eps_abs=1e-10, eps_rel=1e-10, max_iter=20000)
+        assert rc == 0 and np.abs(xo - xs).max() < 1e-7
