@@ -151,6 +151,28 @@ benchlines)     # the round's bench lines, no profiler attached (after `profiles
     WCQP_DIST_BACKEND=gloo timeout -k 10 600 python3 bench.py --gpus 2 --steps 20 --warmup 5 --tick-ticks 200 > $O/bench_gpus2_gloo_rehearsal.json 2>> $O/bench.err || fail "bench gpus 2" $O/bench.err
     last_json $O/bench_*.json
     ;;
+stage)          # CoM / neck Jacobians through LDS a record ahead: semantics of the instruction, parity of the plan forms, A/B against -DWCQP_PLAN_NO_STAGE
+    hipcc -O3 --offload-arch=gfx950 tools/ubench/lds_dma_test.hip -o /tmp/lds_dma_test 2> $O/ubench_build.err || fail "ubench build" $O/ubench_build.err
+    timeout -k 5 60 /tmp/lds_dma_test > $O/lds_dma_test.txt 2>&1 || fail "lds_dma_test" $O/lds_dma_test.txt
+    tail -1 $O/lds_dma_test.txt
+    timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_bench_line.py -m gpu -q -x > $O/pytest.log 2>&1 || fail pytest $O/pytest.log
+    tail -1 $O/pytest.log
+    "$0" ab product nostage
+    ;;
+ab)             # the three bench forms of the plan kernel for each library variant given ("product" = the tree's library), twice, interleaved
+    libs=("$@")
+    for rep in 1 2; do
+      for lib in "${libs[@]}"; do
+        tag=$lib; L=$PWD/walking-controllers_amd/csrc/build/diag/libwcqp_$lib.so
+        [ "$lib" = product ] && L=
+        for cfg in "4096 20 5" "4096 200 20" "65536 50 10"; do
+          read b st w <<< "$cfg"
+          WCQP_LIB_PATH=$L timeout -k 10 400 python bench.py --batch $b --steps $st --warmup $w --no-cpu-baseline --no-tick > $O/${tag}_b${b}_s${st}_$rep.json 2> $O/${tag}_b${b}_s${st}_$rep.err || fail "ab $tag $cfg" $O/${tag}_b${b}_s${st}_$rep.err
+          echo -n "$tag rep $rep: "; last_json $O/${tag}_b${b}_s${st}_$rep.json
+        done
+      done
+    done
+    ;;
 split)          # one combined plan against IK-only + MPC-only plans enqueued together, for the libraries given (product = "")
     for lib in "$@"; do
         tag=${lib:-product}

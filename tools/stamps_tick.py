@@ -31,6 +31,16 @@ lib = wca.capi.lib()
 lib.wcqp_tick_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 wca.capi.check(lib.wcqp_tick_debug_stamps(p._h, buf.ctypes.data_as(C.c_void_p), nw * 16))
 t = buf.reshape(nw, 16).astype(np.float64)
+if kin_mode and os.environ.get("WCQP_KSTAMPS"):
+    # the kinematics phase in detail (library built with -DWCQP_TICK_KSTAMPS): slots 1..9 are its sub-phases
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12]
+    names = ["MPC loads landed, partial sums, stash", "joint rotations (sin / cos)", "pointer jumping (3 rounds) + frame stores", "attached frames in base coordinates",
+             "base pose, attached frames in world coordinates", "own joints in world coordinates, axes, first moments", "frame columns", "prefix sums through LDS",
+             "total, CoM columns", "base vectors, CoM stash, pose block / constants / hand-off loads issued"]
+    seg = np.diff(t[:, order], axis=1)
+    print(json.dumps({"B": B, "ticks": T, "kinematics_detail": True, "median_cycles": dict(zip(names, np.median(seg, 0).tolist())),
+                      "kinematics_median": float(np.median(t[:, 12] - t[:, 0])), "tick_median": float(np.median(t[:, 14] - t[:, 0]))}))
+    sys.exit(0)
 # stamp ids in program order (fused kinematics: 12 = end of the kinematics phase; 13 = MPC(t+1) finished; 14 = post step done)
 order = ([0, 12, 13, 1, 2, 3, 4, 10, 11, 5, 6, 7, 8, 14] if kin_mode else [0, 13, 1, 2, 3, 4, 10, 11, 5, 6, 7, 8, 14])
 names = ((["kinematics (+ MPC loads, partial sums)", "MPC(t+1) arithmetic + glue"] if kin_mode else ["loads issued .. MPC(t+1) arithmetic + glue"]) +

@@ -103,7 +103,14 @@ static_assert(PER_INST * 8 * 4 * 11 <= 160 * 1024, "11 blocks per CU");
 #define WCQP_IK4_KS 4                 // bounds kept replicated in registers (more: the slot-per-lane loop)
 #endif
 
-#if defined(WCQP_TICK_STAMPS)
+#if defined(WCQP_TICK_KSTAMPS)
+// diagnostic build (tools/build_variant.sh kstamps -DWCQP_TICK_KSTAMPS): the KINEMATICS phase of the fused tick in detail - stamps 0, 12 and 14 as
+// below, slots 1..9 are its sub-phases (WCQP_KSTAMP); WCQP_KSTAMPS=1 tools/stamps_tick.py
+#define WCQP_STAMP_AT(k) do { if constexpr (TICK) { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+                              if (lane == 0 && td.stamps) td.stamps[(size_t)blk * 16 + (k)] = t__; } } while (0)
+#define WCQP_STAMP(k) do { if constexpr ((k) == 0 || (k) == 12 || (k) == 14) WCQP_STAMP_AT(k); } while (0)
+#define WCQP_KSTAMP(k) WCQP_STAMP_AT(k)
+#elif defined(WCQP_TICK_STAMPS)
 // diagnostic build (tools/build_variant.sh tstamps -DWCQP_TICK_STAMPS): s_memtime at the phase boundaries of the TICK kernel's body, per
 // workgroup, the last tick of a launch wins (TickDev::stamps; tools/stamps_tick.py)
 #define WCQP_STAMP(k) do { if constexpr (TICK) { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
@@ -113,6 +120,9 @@ static_assert(PER_INST * 8 * 4 * 11 <= 160 * 1024, "11 blocks per CU");
                            if (lane == __ffsll((long long)__ballot(true)) - 1) reinterpret_cast<unsigned long long*>(ferr_out)[(size_t)blockIdx.x * 16 + (k)] = t__; } while (0)
 #else
 #define WCQP_STAMP(k) do { } while (0)
+#endif
+#ifndef WCQP_KSTAMP
+#define WCQP_KSTAMP(k) do { } while (0)
 #endif
 
 // (a, b) -> (rows {a0, a1, b0, b1}, rows {a2, a3, b2, b3}) of the four 16-lane rows (checked on the GPU:
@@ -296,6 +306,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 }
                 if (j < 8) { double* mh = S + K_MH + j * 3; mh[0] = mreg.ha.x; mh[1] = mreg.ha.y; mh[2] = mreg.hb; }
             }
+            WCQP_KSTAMP(1);          // MPC loads landed, partial sums stashed
             const int side = *gait >= td.step_ticks ? 1 : 0;          // (gait: this robot's cycle index (tick + phase0) % (2 step_ticks), carried from tick to tick) 0: left is the stance foot
             if (j < 12) S[k_sd(j)] = *at32(state, iu * (unsigned)(kStateLen * 8) + (unsigned)(24 + side * 12) * 8u + j8);                // desired pose of the anchor sole: p (3), R (9)
             const int cs[2] = {j, var1 ? col1 : 0};
@@ -319,6 +330,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 for (int k = 0; k < 3; ++k) { pa[s_][k] = mt[9 + k]; axl[k] = mt[12 + k]; }
                 joint_rotation(R0, axl, s_ == 0 ? q0 : q1, Ra[s_]);
             }
+            WCQP_KSTAMP(2);          // joint rotations (sin / cos) done
             // the tree in base coordinates by pointer jumping (kin.hip): after round r a frame is relative to its 2^(r+1)-th ancestor
             const int n_rounds = td.kin_rounds;
 #pragma unroll
@@ -364,6 +376,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
             }
             }
             wcqp::wave_lds_fence();
+            WCQP_KSTAMP(3);          // pointer jumping done, frames stored
             // attached frames (left sole, right sole, neck) in base coordinates: lanes 0..2
             const int fi = j < 3 ? j : 0;
             double Rf[9], pf[3];
@@ -385,6 +398,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 }
             }
             wcqp::wave_lds_fence();
+            WCQP_KSTAMP(4);          // attached frames in base coordinates
             // base pose from the anchor foot: world_T_base = world_T_sole,desired * (base_T_sole)^-1
             double pb[3], Rb[9];
             {
@@ -416,6 +430,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
                 for (int k = 0; k < 3; ++k) F[9 + k] = pg[k];
             }
+            WCQP_KSTAMP(5);          // base pose, attached frames in world coordinates
             // own joints in world coordinates, their axes, link first moments {m c, m}
             double pw[2][3], aw[2][3], e4[2][4];
 #pragma unroll
@@ -440,6 +455,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 e4[s_][3] = mj;
             }
             wcqp::wave_lds_fence();          // FR is complete; the joint frames are dead: the prefix sums overlay them
+            WCQP_KSTAMP(6);          // own joints in world coordinates
             // ---- frame columns: joint c is on the path of at most one of the three frames (compact_offset: kind)
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) {
@@ -459,6 +475,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                     a[15 + r] = mN * aw[s_][r];
                 }
             }
+            WCQP_KSTAMP(7);          // frame columns
             // ---- subtree first moments: the joint numbering is depth-first, a subtree is an index range; inclusive prefix sums
             // over joints 0..15 (slot 0, a DPP row scan) and 16.. (slot 1, offset by the row's total)
             double* PS = S + K_TW;               // [32][4]
@@ -472,6 +489,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
                 st2(PS + (16 + j) * 4, p1s[0] + t01.x, p1s[1] + t01.y); st2(PS + (16 + j) * 4 + 2, p1s[2] + t23.x, p1s[3] + t23.y);
                 wcqp::wave_lds_fence();
             }
+            WCQP_KSTAMP(8);          // prefix sums in LDS
             double tot[4], ctot[3];
             {
                 const double* rt = kmodel + wcqp_tick::kKinTabRoot;
@@ -502,6 +520,7 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
 #pragma unroll
                 for (int r = 0; r < 3; ++r) a[12 + r] = mv * lin[r];
             }
+            WCQP_KSTAMP(9);          // CoM columns
             // the vectors the base blocks [I -S(p); 0 I] are made of: p_left - p_base, p_right - p_base, p_com - p_base
             double kdv[9];
             {
