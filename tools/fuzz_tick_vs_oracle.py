@@ -2,7 +2,7 @@
 """Closed-loop fuzz: the tick pipeline (fused kinematics, and constant Jacobians) against oracle/tick_spec.py on robots and horizons the
 GPU suite does not have time for: several groups of robots (different `first` offsets = different synthetic robots), 300 ticks each.
 Same tolerances as tests/test_tick_pipeline.py (u0 1e-9, dq 1e-8, q_des 1e-9; identical failure bookkeeping).  Prints one JSON line per case.
-   python tools/fuzz_tick_vs_oracle.py [groups] [robots per group] [ticks]"""
+   python tools/fuzz_tick_vs_oracle.py [groups] [robots per group] [ticks] [first group]     (first group: robots no earlier run has seen; round 3 ran groups 1..4)"""
 import json, os, sys, time
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,12 +12,13 @@ from oracle import qp_spec as qs, tick_spec as ts
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+G0 = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 S = wca.synth
 p = ts.TickParams()
 worst = {"u0": 0.0, "dq": 0.0, "q_des": 0.0}
 t0 = time.time()
 for g in range(G):
-    first = 1000 * (g + 1)
+    first = 1000 * (g + G0)
     # ---- fused kinematics on the walk scenario
     kin = wca.KinModel(S.icub_like_model())
     kb = S.synth_walk_kin_batch(B, first=first)

@@ -159,6 +159,22 @@ stage)          # CoM / neck Jacobians through LDS a record ahead: semantics of 
     tail -1 $O/pytest.log
     "$0" ab product nostage
     ;;
+fuzz)           # both fuzz tools on the final kernels, on instances no earlier round has seen (seed offset 4000; robot groups 5..8), all three parameter sets
+    timeout -k 10 1000 python tools/fuzz_vs_oracle.py 42 256 4000 > $O/fuzz_vs_oracle.jsonl 2> $O/fuzz.err || fail fuzz $O/fuzz.err
+    tail -1 $O/fuzz_vs_oracle.jsonl
+    timeout -k 10 1000 python tools/fuzz_tick_vs_oracle.py 4 24 300 5 > $O/fuzz_tick_vs_oracle.jsonl 2> $O/fuzz_tick.err || fail fuzz_tick $O/fuzz_tick.err
+    tail -1 $O/fuzz_tick_vs_oracle.jsonl
+    ;;
+tstamps)        # the tick kernel by phase, both forms (library: tools/build_variant.sh tstamps -DWCQP_TICK_STAMPS)
+    for m in kin tables; do
+      WCQP_LIB_PATH=$PWD/walking-controllers_amd/csrc/build/diag/libwcqp_tstamps.so timeout -k 10 300 python tools/stamps_tick.py 8192 200 $m > $O/tstamps_$m.json 2> $O/tstamps_$m.err || fail "tstamps $m" $O/tstamps_$m.err
+      cat $O/tstamps_$m.json
+    done
+    ;;
+kstamps)        # the kinematics phase of the fused tick by sub-phase (s_memtime; library built with tools/build_variant.sh kstamps -DWCQP_TICK_KSTAMPS -DWCQP_TICK_STAMPS)
+    WCQP_KSTAMPS=1 WCQP_LIB_PATH=$PWD/walking-controllers_amd/csrc/build/diag/libwcqp_kstamps.so timeout -k 10 300 python tools/stamps_tick.py 8192 200 kin > $O/kstamps.json 2> $O/kstamps.err || fail kstamps $O/kstamps.err
+    cat $O/kstamps.json
+    ;;
 ab)             # the three bench forms of the plan kernel for each library variant given ("product" = the tree's library), twice, interleaved
     libs=("$@")
     for rep in 1 2; do

@@ -48,4 +48,5 @@ names = ((["kinematics (+ MPC loads, partial sums)", "MPC(t+1) arithmetic + glue
 seg = np.diff(t[:, order], axis=1)
 print(json.dumps({"B": B, "ticks": T, "kinematics": kin_mode, "median_cycles": dict(zip(names, np.median(seg, 0).tolist())),
                   "p90_active_set": float(np.percentile(seg[:, -2], 90)), "tick_median": float(np.median(t[:, 14] - t[:, 0])),
+                  "end_of_tick_fence_median": float(np.median(t[:, 15] - t[:, 14])), "end_of_tick_fence_p90": float(np.percentile(t[:, 15] - t[:, 14], 90)),
                   "tick_p90": float(np.percentile(t[:, 14] - t[:, 0], 90))}))

@@ -104,7 +104,7 @@ static_assert(PER_INST * 8 * 4 * 11 <= 160 * 1024, "11 blocks per CU");
 #endif
 
 #if defined(WCQP_TICK_KSTAMPS)
-// diagnostic build (tools/build_variant.sh kstamps -DWCQP_TICK_KSTAMPS): the KINEMATICS phase of the fused tick in detail - stamps 0, 12 and 14 as
+// diagnostic build (tools/build_variant.sh kstamps -DWCQP_TICK_KSTAMPS -DWCQP_TICK_STAMPS): the KINEMATICS phase of the fused tick in detail - stamps 0, 12 and 14 as
 // below, slots 1..9 are its sub-phases (WCQP_KSTAMP); WCQP_KSTAMPS=1 tools/stamps_tick.py
 #define WCQP_STAMP_AT(k) do { if constexpr (TICK) { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
                               if (lane == 0 && td.stamps) td.stamps[(size_t)blk * 16 + (k)] = t__; } } while (0)
@@ -1641,6 +1641,13 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef WCQP_TICK_STAMPS
+            {   // slot 15: behind the fence (slot 14 is the end of the post step: the difference is what the fence waits for)
+                unsigned long long t__;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory");
+                if (threadIdx.x == 0 && td.stamps) td.stamps[(size_t)blockIdx.x * 16 + 15] = t__;
+            }
+#endif
         }
         // advanceReferenceSignals (WalkingModule.cpp:816): the next launch reads the other copy of the tick index
         if (blockIdx.x == 0 && threadIdx.x == 0) td.tick2[1 - phase] = t0 + n_inner;
