@@ -175,6 +175,32 @@ kstamps)        # the kinematics phase of the fused tick by sub-phase (s_memtime
     WCQP_KSTAMPS=1 WCQP_LIB_PATH=$PWD/walking-controllers_amd/csrc/build/diag/libwcqp_kstamps.so timeout -k 10 300 python tools/stamps_tick.py 8192 200 kin > $O/kstamps.json 2> $O/kstamps.err || fail kstamps $O/kstamps.err
     cat $O/kstamps.json
     ;;
+xcd)            # XCD-aware robot-group order of the plan kernel against the plain order (-DWCQP_PLAN_NO_XCD_MAP): parity, three bench forms, HBM fetch bytes
+    timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_bench_line.py -m gpu -q -x > $O/pytest.log 2>&1 || fail pytest $O/pytest.log
+    tail -1 $O/pytest.log
+    "$0" ab product noxcd || exit 1
+    R0=$PWD; cd /tmp && export TMPDIR=/tmp
+    for lib in product noxcd; do
+        L=$R0/walking-controllers_amd/csrc/build/diag/libwcqp_$lib.so; [ $lib = product ] && L=$R0/walking-controllers_amd/libwcqp.so
+        export WCQP_LIB_PATH=$L
+        for bs in "4096 88" "65536 24"; do
+            read b st <<< "$bs"
+            timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R0/$O/pmc_$lib/bench_${b}_FETCH_SIZE -- python3 $R0/bench.py --steps $st --warmup $st --repeats 1 --batch $b --no-cpu-baseline --no-tick > $R0/$O/pmc_${lib}_$b.log 2>&1 < /dev/null || fail "pmc $lib $b" $R0/$O/pmc_${lib}_$b.log
+        done
+        unset WCQP_LIB_PATH
+        ( cd $R0 && python3 tools/pmc/summarize.py $O/pmc_$lib > $O/pmc_summary_$lib.json 2> $O/pmc_summary_$lib.err; rm -rf $O/pmc_$lib )
+    done
+    cd $R0
+    python3 - $O <<'PY'
+import json, sys
+O = sys.argv[1]
+for lib in ("product", "noxcd"):
+    d = json.load(open("%s/pmc_summary_%s.json" % (O, lib)))
+    for run, ks in d.items():
+        k = ks.get("qp_plan_kernel", {}).get("FETCH_SIZE")
+        if k: print(lib, run, "FETCH_SIZE mean per launch %.6g (KiB, to be doubled on gfx950: tools/pmc/make_traffic.py) over %d launches" % (k["mean_per_launch"], k["launches"]))
+PY
+    ;;
 ab)             # the three bench forms of the plan kernel for each library variant given ("product" = the tree's library), twice, interleaved
     libs=("$@")
     for rep in 1 2; do

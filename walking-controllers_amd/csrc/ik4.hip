@@ -1586,6 +1586,17 @@ void ik4_body(const IkDeviceParams* __restrict__ prm, int batch,
     }
 }
 
+// XCD-aware order of the robot groups of a launch: the hardware hands workgroup b to XCD b mod 8, each XCD with an L2 of its own, and robot
+// groups that are neighbours in memory share the cache lines their blocks meet in (a group's share of a Jacobian array is 43.5 or 21.75
+// lines) - with groups g, g + 1, ... on eight different XCDs each of those lines comes from HBM twice.  XCD x takes the CONTIGUOUS eighth x
+// of the groups instead.  A permutation of the groups; counts that are not a multiple of 8 keep the plain order.
+__device__ __forceinline__ int xcd_group(int b, int groups) {
+#ifndef WCQP_PLAN_NO_XCD_MAP
+    if ((groups & 7) == 0) return (b & 7) * (groups >> 3) + (b >> 3);
+#endif
+    return b;
+}
+
 // skip_last_mpc: the last tick of the launch does not run the MPC chain of the tick after it (the last launch of a
 // wcqp_tick_run call: between calls nothing is ahead of anything, so the host may change the trajectories or read the state).
 // n_inner (tick pipeline): ticks this launch runs.  The robots of a wave depend on no other wave's - the launch of a tick
@@ -1652,7 +1663,7 @@ void ik4_kernel(const IkDeviceParams* __restrict__ prm, int batch,
         // advanceReferenceSignals (WalkingModule.cpp:816): the next launch reads the other copy of the tick index
         if (blockIdx.x == 0 && threadIdx.x == 0) td.tick2[1 - phase] = t0 + n_inner;
     } else {
-        ik4_body<TICK, JSRC>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem, (int)blockIdx.x);
+        ik4_body<TICK, JSRC>(prm, batch, JL, JR, JN, JC, qpos, state, dq_out, status_out, alo_out, aup_out, ferr_out, iters_out, wcqp_tick::TickDev{}, smem, xcd_group((int)blockIdx.x, (int)gridDim.x));
     }
 }
 
@@ -1689,7 +1700,7 @@ void qp_pair_kernel(const IkDeviceParams* __restrict__ prm, int batch,
     // IK workgroups first: they are the long ones.  (Alternating the two kinds in dispatch order was measured: the MPC waves
     // then take slots from IK waves that have not started yet - 17.7 vs 14.5 us at 4096 robots, 158 vs 116 us at 65536.)
     const bool is_mpc = (int)blockIdx.x >= ik_blocks;
-    const int blk = is_mpc ? (int)blockIdx.x - ik_blocks : (int)blockIdx.x;
+    const int blk = is_mpc ? (int)blockIdx.x - ik_blocks : xcd_group((int)blockIdx.x, ik_blocks);
     if (is_mpc) {
         static_assert(wcqp_mpc::kInstPerWave * WCQP_HULL_ROWS * 4 <= 4 * PER_INST, "the hull rows fit the IK's LDS");
         double (*s_hull)[WCQP_HULL_ROWS][4] = reinterpret_cast<double (*)[WCQP_HULL_ROWS][4]>(&smem[0][0]);
@@ -1753,6 +1764,15 @@ void plan_walk(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_
         return total;
     };
     int r = (int)blockIdx.x / groups, blk = (int)blockIdx.x % groups;
+#ifndef WCQP_PLAN_NO_XCD_MAP
+    // XCD-aware (xcd_group above): XCD x walks the contiguous eighth x of the robot groups - its k-th workgroup is way k / n, group x n + k mod n.
+    // PMC: the launch fetches 3 % fewer bytes (the 4 % by which its traffic exceeded its algorithmic bytes), +0.5 to +1.5 % QP/s
+    // (profiles/r04_xcd_map_ab.txt).
+    if ((groups & 7) == 0) {
+        const int n = groups >> 3, x = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+        r = k / n; blk = x * n + k % n;
+    }
+#endif
     if (dynamic) {
         const unsigned u = draw();
         r = u < total ? (int)(u % (unsigned)n_steps) : n_steps; blk = u < total ? (int)(u / (unsigned)n_steps) : 0;
