@@ -29,7 +29,9 @@ suite)          # the GPU suite, smoke, the driver's bench command
     tail -1 $O/pytest.log
     python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || fail smoke $O/smoke.log
     tail -1 $O/smoke.log
+    T0=$SECONDS
     timeout -k 10 500 python bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err || fail bench $O/bench_driver.err
+    echo "driver bench command: $((SECONDS - T0)) s wall"
     last_json $O/bench_driver.json
     ;;
 bench)          # new bench-related tests, the driver's command, a 2-rank gloo rehearsal
