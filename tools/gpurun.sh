@@ -203,6 +203,21 @@ for lib in ("product", "noxcd"):
         if k: print(lib, run, "FETCH_SIZE mean per launch %.6g (KiB, to be doubled on gfx950: tools/pmc/make_traffic.py) over %d launches" % (k["mean_per_launch"], k["launches"]))
 PY
     ;;
+queue)          # the work-queue form of the plan with fewer steal attempts at the exit (-DWCQP_PLAN_STEAL=n) against the fixed ways, driver form and 200 steps
+    libs=("$@")
+    for rep in 1 2; do
+      for lib in "${libs[@]}"; do
+        L=$PWD/walking-controllers_amd/csrc/build/diag/libwcqp_$lib.so; [ "$lib" = product ] && L=
+        for q in 0 1; do
+          for cfg in "20 5" "200 20"; do
+            read st w <<< "$cfg"
+            WCQP_LIB_PATH=$L timeout -k 10 400 python bench.py --steps $st --warmup $w --plan-queue $q --no-cpu-baseline --no-tick > $O/${lib}_q${q}_s${st}_$rep.json 2> $O/${lib}_q${q}_s${st}_$rep.err || fail "queue $lib $q $cfg" $O/${lib}_q${q}_s${st}_$rep.err
+            echo -n "$lib queue=$q rep $rep: "; last_json $O/${lib}_q${q}_s${st}_$rep.json
+          done
+        done
+      done
+    done
+    ;;
 ab)             # the three bench forms of the plan kernel for each library variant given ("product" = the tree's library), twice, interleaved
     libs=("$@")
     for rep in 1 2; do

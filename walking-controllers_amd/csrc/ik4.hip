@@ -1754,7 +1754,12 @@ void plan_walk(const IkDeviceParams* __restrict__ prm, int batch, const wcqp_qp_
     unsigned home = blockIdx.x % wcqp_ik::kPlanQueues;
     // the next unit of any queue, starting at `home` (synchronous): total when every queue has run out
     auto draw = [&]() -> unsigned {
-        for (unsigned tried = 0; tried < wcqp_ik::kPlanQueues; ++tried) {
+#ifndef WCQP_PLAN_STEAL
+#define WCQP_PLAN_STEAL (wcqp_ik::kPlanQueues - 1u)
+#endif
+        // (every queue is the HOME of gridDim.x / kPlanQueues waves, which draw from it until it is empty: a queue is drained whether or
+        // not anybody else visits it, so how many OTHER queues a wave tries before it leaves is a matter of balance, not of correctness)
+        for (unsigned tried = 0; tried <= WCQP_PLAN_STEAL; ++tried) {
             unsigned k = 0;
             if (threadIdx.x == 0) k = __hip_atomic_fetch_add(queue + home * QS + z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)k) * wcqp_ik::kPlanQueues + home;
