@@ -218,6 +218,29 @@ queue)          # the work-queue form of the plan with fewer steal attempts at t
       done
     done
     ;;
+pmc2)           # instruction-cache and LDS-stall counters of the plan kernel and the fused tick (one group per run, --kernel-trace only)
+    R0=$PWD; cd /tmp && export TMPDIR=/tmp
+    P1="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"
+    P2="SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES"
+    P3="SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_LOAD_BANDWIDTH SQ_INSTS_LDS_STORE_BANDWIDTH SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES"
+    n=1
+    for P in "$P1" "$P2" "$P3"; do
+        timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R0/$O/pmc/plan_4096_p$n -- python3 $R0/bench.py --steps 88 --warmup 88 --repeats 1 --batch 4096 --no-cpu-baseline --no-tick > $R0/$O/pmc_plan_p$n.log 2>&1 < /dev/null || fail "pmc plan $n" $R0/$O/pmc_plan_p$n.log
+        timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $R0/$O/pmc/tickkin_8192_p$n -- python3 $R0/bench.py --workload tick --batch 8192 --steps 200 --warmup 24 --no-cpu-baseline > $R0/$O/pmc_tickkin_p$n.log 2>&1 < /dev/null || fail "pmc tick $n" $R0/$O/pmc_tickkin_p$n.log
+        n=$((n+1))
+    done
+    cd $R0
+    python3 tools/pmc/summarize.py $O/pmc > $O/pmc2_summary.json 2> $O/pmc2_summary.err
+    rm -rf $O/pmc
+    python3 - $O/pmc2_summary.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for run, ks in sorted(d.items()):
+    for k, c in ks.items():
+        if k in ("qp_plan_kernel", "ik4_tick_kernel"):
+            print(run, k, {n: "%.4g" % v["total"] for n, v in c.items()})
+PY
+    ;;
 ab)             # the three bench forms of the plan kernel for each library variant given ("product" = the tree's library), twice, interleaved
     libs=("$@")
     for rep in 1 2; do
