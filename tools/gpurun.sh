@@ -154,6 +154,8 @@ benchlines)     # the round's bench lines, no profiler attached (after `profiles
     last_json $O/bench_*.json
     ;;
 stage)          # CoM / neck Jacobians through LDS a record ahead: semantics of the instruction, parity of the plan forms, A/B against -DWCQP_PLAN_NO_STAGE
+                # NEEDS profiles/r04_lds_stage.patch applied (git apply) and both libraries rebuilt: the experiment was negative, the code is not in the tree
+    grep -q WCQP_PLAN_NO_STAGE walking-controllers_amd/csrc/ik4.hip || { echo 'stage: apply profiles/r04_lds_stage.patch, rebuild, tools/build_variant.sh nostage -DWCQP_PLAN_NO_STAGE first'; exit 1; }
     hipcc -O3 --offload-arch=gfx950 tools/ubench/lds_dma_test.hip -o /tmp/lds_dma_test 2> $O/ubench_build.err || fail "ubench build" $O/ubench_build.err
     timeout -k 5 60 /tmp/lds_dma_test > $O/lds_dma_test.txt 2>&1 || fail "lds_dma_test" $O/lds_dma_test.txt
     tail -1 $O/lds_dma_test.txt
