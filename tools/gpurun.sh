@@ -82,7 +82,7 @@ PY
     ;;
 pipe)           # record-ahead Jacobian loads in the plan kernel, A/B against the same walk without them (WCQP_PLAN_NO_PIPE). NEEDS profiles/r04_record_ahead.patch
                 # applied to csrc/ik4.hip (git apply) and a rebuild: the experiment was negative and the code is not in the tree (profiles/r04_record_ahead_ab.txt)
-    grep -q WCQP_PLAN_NO_PIPE walking-controllers_amd/csrc/*.hip || { echo 'pipe: apply profiles/r04_record_ahead.patch and rebuild first'; exit 1; }
+    grep -q WCQP_PLAN_NO_PIPE walking-controllers_amd/csrc/*.hip || { echo 'pipe: check out csrc of commit dd95896, apply profiles/r04_record_ahead.patch and rebuild first'; exit 1; }
     timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_bench_line.py -m gpu -q -x > $O/pytest.log 2>&1 || fail pytest $O/pytest.log
     tail -1 $O/pytest.log
     for rep in 1 2; do
@@ -155,7 +155,7 @@ benchlines)     # the round's bench lines, no profiler attached (after `profiles
     ;;
 stage)          # CoM / neck Jacobians through LDS a record ahead: semantics of the instruction, parity of the plan forms, A/B against -DWCQP_PLAN_NO_STAGE
                 # NEEDS profiles/r04_lds_stage.patch applied (git apply) and both libraries rebuilt: the experiment was negative, the code is not in the tree
-    grep -q WCQP_PLAN_NO_STAGE walking-controllers_amd/csrc/ik4.hip || { echo 'stage: apply profiles/r04_lds_stage.patch, rebuild, tools/build_variant.sh nostage -DWCQP_PLAN_NO_STAGE first'; exit 1; }
+    grep -q WCQP_PLAN_NO_STAGE walking-controllers_amd/csrc/ik4.hip || { echo 'stage: check out csrc of commit 620ab08, apply profiles/r04_lds_stage.patch, rebuild, tools/build_variant.sh nostage -DWCQP_PLAN_NO_STAGE first'; exit 1; }
     hipcc -O3 --offload-arch=gfx950 tools/ubench/lds_dma_test.hip -o /tmp/lds_dma_test 2> $O/ubench_build.err || fail "ubench build" $O/ubench_build.err
     timeout -k 5 60 /tmp/lds_dma_test > $O/lds_dma_test.txt 2>&1 || fail "lds_dma_test" $O/lds_dma_test.txt
     tail -1 $O/lds_dma_test.txt
