@@ -801,7 +801,7 @@ def tick_object(c):
                 "value": value, "unit": "QP/s", "us_per_tick": 1e6 * elapsed / T, "kernel_us_per_tick": us,
                 "per_tick_kinematics": kin_mode,
                 "launch": "ik4_kernel<TICK%s>: 1 launch for the %d ticks (+ tick_mpc_prime_kernel)" % (", fused kinematics" if kin_mode else "", T),
-                "roofline": {"bound": "issue", "kernel_bound_note": "instruction issue of two waves per SIMD at 256 VGPRs, not bytes (DESIGN.md 8): the HBM fractions below are reported, not the limit",
+                "roofline": {"bound": "latency", "kernel_bound_note": "one wave's chain of dependent LDS round trips and arithmetic with ONE other wave per SIMD to hide behind (256 VGPRs; VALU and LDS pipe each a little over half busy), not bytes (DESIGN.md 8.2): the HBM fractions below are reported, not the limit",
                              "achieved": 6296 * B / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 6296 * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_basis": "SURVEY.md 8d: 6296 B per robot-tick (1056 MPC + 5240 IK), per TICK",
                              "own_hbm_bytes_per_robot_tick": own, "own_bytes_from": "PMC (profiles/traffic.json)" if own_pmc else "model of the pipeline's reads and writes (no current PMC pass)",

@@ -31,7 +31,7 @@ def test_default_line_carries_roofline_tick_and_both_cpu_baselines():
     for name in ("fused_kinematics", "constant_jacobians"):
         t = d["tick"][name]
         assert "error" not in t, t
-        assert t["value"] > 0 and t["us_per_tick"] > 0 and t["roofline"]["bound"] == "issue" and t["roofline"]["own_hbm_bytes_per_robot_tick"] > 0
+        assert t["value"] > 0 and t["us_per_tick"] > 0 and t["roofline"]["bound"] == "latency" and t["roofline"]["own_hbm_bytes_per_robot_tick"] > 0
         assert t["solved"]["ticks_executed"] == 60 + 24 and t["solved"]["mpc_fail"] == 0
         oc = t["oracle_check"]
         assert oc["ok"] is True and oc["ticks"] == 16 and len(oc["robots"]) >= 5 and oc["max_abs_err_u0"] <= 1e-9 and oc["max_abs_err_dq"] <= 1e-8, oc
