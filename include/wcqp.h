@@ -547,8 +547,9 @@ int wcqp_tick_splice_reference(wcqp_tick_t h, int32_t from_tick, int32_t n_stage
  * WalkingQPIK::setRobotState (:373) of WM/src/WalkingModule.cpp. */
 int wcqp_tick_set_feedback_device(wcqp_tick_t h, const double* dcm_meas, const double* com_meas, const double* zmp_meas,
                                   const double* q_meas, void* stream);
-/* the same from HOST pointers: staged through device memory of the handle and enqueued on the NULL stream before the call returns
- * (the host arrays may be released at once); run the tick on the NULL stream, or on one that synchronises with it */
+/* the same from HOST pointers: staged through device memory of the handle and IN PLACE when the call returns (it synchronises: the host
+ * arrays may be released at once, and the tick may then be run on any stream, a non-blocking one included).  With the device form the
+ * caller orders the copy kernel's stream before the stream of the run call (the same stream does). */
 int wcqp_tick_set_feedback_host(wcqp_tick_t h, const double* dcm_meas, const double* com_meas, const double* zmp_meas, const double* q_meas);
 int wcqp_tick_download(wcqp_tick_t h, const wcqp_tick_outputs* out);             /* synchronises     */
 

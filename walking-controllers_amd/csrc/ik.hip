@@ -302,6 +302,7 @@ int wcqp_qp_plan_create(wcqp_mpc_t mpc, wcqp_ik_t ik, int32_t batch, int32_t n_s
             if (p->d_queue) (void)hipFree(p->d_queue);
             (void)hipFree(p->d_recs); delete p; return WCQP_E_HIP;
         }
+        (void)hipStreamSynchronize(nullptr);          // (hipMemset does not wait; wcqp_qp_plan_enqueue may name a non-blocking stream)
     }
     *out = p;
     return WCQP_OK;

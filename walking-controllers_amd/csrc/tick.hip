@@ -339,6 +339,9 @@ int wcqp_tick_upload(wcqp_tick_t h, const wcqp_tick_inputs* in) {
     WCQP_HIP_TRY(hipMemset(d.mpc_fail, 0, B * 8)); WCQP_HIP_TRY(hipMemset(d.ik_fail, 0, B * 8));
     WCQP_HIP_TRY(hipMemset(d.hot_try, 0, B * 8)); WCQP_HIP_TRY(hipMemset(d.hot_hit, 0, B * 8));
     WCQP_HIP_TRY(hipMemset(h->ik_lo, 0, B * 4)); WCQP_HIP_TRY(hipMemset(h->ik_up, 0, B * 4));      // no previous active set at tick 0
+    // (hipMemset does not wait, and the copies / kernels above ran on the NULL stream: the run call that follows may name a non-blocking
+    // stream - wcqp_stream_create makes such - which would not wait for them either)
+    WCQP_HIP_TRY(hipDeviceSynchronize());
     h->uploaded = true;
     h->ticks_enqueued = 0;
     h->phase = 0;
@@ -368,7 +371,12 @@ int wcqp_tick_set_feedback_host(wcqp_tick_t h, const double* dcm_meas, const dou
     WCQP_HIP_TRY(hipMemcpy(st + 2 * B, com_meas, B * 16, hipMemcpyHostToDevice));
     WCQP_HIP_TRY(hipMemcpy(st + 4 * B, zmp_meas, B * 16, hipMemcpyHostToDevice));
     if (q_meas) WCQP_HIP_TRY(hipMemcpy(st + 6 * B, q_meas, B * kDof * 8, hipMemcpyHostToDevice));
-    return wcqp_tick_set_feedback_device(h, st, st + 2 * B, st + 4 * B, q_meas ? st + 6 * B : nullptr, nullptr);
+    const int rc = wcqp_tick_set_feedback_device(h, st, st + 2 * B, st + 4 * B, q_meas ? st + 6 * B : nullptr, nullptr);
+    if (rc != WCQP_OK) return rc;
+    // the copy kernel ran on the NULL stream; the tick that consumes the feedback may be enqueued on ANY stream - a non-blocking one
+    // (wcqp_stream_create) would not wait for it - so the feedback is in place when this call returns, and the staging rows are free
+    WCQP_HIP_TRY(hipStreamSynchronize(nullptr));
+    return WCQP_OK;
 }
 
 int wcqp_tick_run(wcqp_tick_t h, int32_t n_ticks, int32_t use_graph, void* stream) {
