@@ -487,7 +487,7 @@ class TickPipeline:
         check(lib().wcqp_tick_set_feedback_device(self._h, dcm_meas, com_meas, zmp_meas, q_meas or None, stream or None), "wcqp_tick_set_feedback_device")
 
     def set_feedback_host(self, dcm_meas, com_meas, zmp_meas, q_meas=None):
-        """External feedback from host arrays ([B][2] each, q_meas [B][dof] or None): staged and enqueued on the NULL stream."""
+        """External feedback from host arrays ([B][2] each, q_meas [B][dof] or None): in place when the call returns (the run may name any stream)."""
         a = [_f64(x) for x in (dcm_meas, com_meas, zmp_meas)]
         q = None if q_meas is None else _f64(q_meas)
         assert all(x.shape == (self.batch, 2) for x in a) and (q is None or q.shape == (self.batch, self.dof))
